@@ -1,0 +1,77 @@
+"""Loader of the HIP C-ABI library (csrc/libatmrt.so).  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libatmrt.so")
+
+_lib = None
+
+
+class AtmrtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"atmrt status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def build(force=False):
+    """Compile libatmrt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", CSRC], check=True)
+    return LIB_PATH
+
+
+def load():
+    """dlopen libatmrt.so and declare every entry point of include/atmrt.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950); "
+                          "this package has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, dbl, sz = C.c_void_p, C.c_int32, C.c_double, C.c_size_t
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "atmrt_abi_version": (C.c_int, []),
+        "atmrt_abi_sizeof": (sz, [C.c_int]),
+        "atmrt_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "atmrt_ctx_destroy": (None, [vp]),
+        "atmrt_last_error": (C.c_char_p, [vp]),
+        "atmrt_terrain_load_dir": (C.c_int, [vp, C.c_char_p, C.POINTER(i32)]),
+        "atmrt_terrain_add_tile": (C.c_int, [vp, i32, i32, i32, i32, vp]),
+        "atmrt_terrain_clear": (C.c_int, [vp]),
+        "atmrt_terrain_get_elev": (C.c_int, [vp, sz, vp, vp, vp, vp]),
+        "atmrt_params_default": (None, [C.POINTER(_abi.Params)]),
+        "atmrt_atmosphere_us76": (None, [C.POINTER(_abi.Atmosphere)]),
+        "atmrt_set_params": (C.c_int, [vp, C.POINTER(_abi.Params)]),
+        "atmrt_set_atmosphere": (C.c_int, [vp, C.POINTER(_abi.Atmosphere)]),
+        "atmrt_objects_set": (C.c_int, [vp, C.POINTER(_abi.Object), sz]),
+        "atmrt_generate": (C.c_int, [vp, C.POINTER(_abi.Result)]),
+        "atmrt_result_free": (None, [C.POINTER(_abi.Result)]),
+        "atmrt_generate_device": (C.c_int, [vp, C.POINTER(_abi.DevicePlanes), C.POINTER(C.c_uint64), pd]),
+        "atmrt_last_timings": (C.c_int, [vp, C.POINTER(_abi.Timings)]),
+        "atmrt_ray_paths": (C.c_int, [vp, dbl, sz, vp, i32, dbl, sz, vp, vp]),
+        "atmrt_atmosphere_sample": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
+        "atmrt_coords_at_dist": (C.c_int, [vp, dbl, dbl, dbl, sz, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if L.atmrt_abi_version() != 1:
+        raise ImportError("libatmrt.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED = ["atmrt_abi_version", "atmrt_ctx_create", "atmrt_ctx_destroy", "atmrt_last_error", "atmrt_terrain_load_dir",
+            "atmrt_terrain_add_tile", "atmrt_terrain_clear", "atmrt_terrain_get_elev", "atmrt_params_default",
+            "atmrt_atmosphere_us76", "atmrt_set_params", "atmrt_set_atmosphere", "atmrt_objects_set", "atmrt_generate",
+            "atmrt_result_free", "atmrt_generate_device", "atmrt_last_timings", "atmrt_ray_paths", "atmrt_atmosphere_sample",
+            "atmrt_coords_at_dist"]

@@ -1,0 +1,871 @@
+// atmrt_api.hip — implementation of the C ABI in include/atmrt.h: context, terrain store (own DTED
+// parser), frame set-up and the launch sequence of each generator.  There is no CPU compute path:
+// without a HIP device atmrt_ctx_create fails with ATMRT_ERR_NO_DEVICE.
+#include <dirent.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "atmrt_kernels.h"
+
+using namespace atmrt;
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_create_error = "";
+
+struct HostTile {
+  int n_lat = 0, n_lon = 0;
+  std::vector<int16_t> posts; // [n_lat][n_lon]
+};
+
+// grow-only device buffer
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(ptr); }
+};
+
+} // namespace
+
+struct atmrt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev[10] = {};
+  atmrt_timings_t timings{};
+  std::string error;
+
+  // terrain (Terrain, terrain/mod.rs:55-57): tiles keyed by integer degrees
+  std::map<std::pair<int, int>, HostTile> tiles;
+  bool terrain_dirty = true;
+  DevBuf d_posts, d_tiles, d_cells;
+  TerrainView tv{};
+
+  bool have_params = false;
+  atmrt_params_t params{};
+  atmrt_atmosphere_t atm_def{};
+  AtmTable atm{};
+  Earth earth{};
+  Pinhole pinhole{};
+  std::vector<double> xs;
+  int n_t = 0, n_path_cap = 0;
+  bool xs_dirty = true;
+
+  std::vector<atmrt_object_t> objects;
+
+  // workspace
+  DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
+      d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    error = buf;
+    return code;
+  }
+};
+
+#define HIP_TRY(ctx, expr)                                                                               \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return (ctx)->fail(ATMRT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// DTED (MIL-PRF-89020B) — replaces crate dted 0.2's read_dted / read_dted_header (terrain/mod.rs:24,86)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr long DTED_DATA_OFFSET = 3428; // UHL 80 + DSI 648 + ACC 2700
+
+int parse_uint(const unsigned char* p, int n) {
+  int v = 0;
+  for (int i = 0; i < n; i++) {
+    if (p[i] < '0' || p[i] > '9') return -1;
+    v = v * 10 + (p[i] - '0');
+  }
+  return v;
+}
+
+bool parse_angle(const unsigned char* p, double* deg) { // DDDMMSSH
+  int d = parse_uint(p, 3), m = parse_uint(p + 3, 2), s = parse_uint(p + 5, 2);
+  if (d < 0 || m < 0 || s < 0) return false;
+  double v = (double)d + (double)m / 60.0 + (double)s / 3600.0;
+  if (p[7] == 'S' || p[7] == 'W') v = -v;
+  else if (p[7] != 'N' && p[7] != 'E') return false;
+  *deg = v;
+  return true;
+}
+
+// returns 0, or a negative status with msg filled
+int read_dted(const char* path, int* lat0, int* lon0, HostTile* tile, std::string* msg) {
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    *msg = std::string("cannot open ") + path;
+    return ATMRT_ERR_IO;
+  }
+  unsigned char uhl[80];
+  double olat = 0, olon = 0;
+  int rc = ATMRT_ERR_FORMAT;
+  std::vector<unsigned char> rec;
+  do {
+    if (fread(uhl, 1, 80, f) != 80 || memcmp(uhl, "UHL1", 4) != 0) break;
+    if (!parse_angle(uhl + 4, &olon) || !parse_angle(uhl + 12, &olat)) break;
+    int nlon = parse_uint(uhl + 47, 4), nlat = parse_uint(uhl + 51, 4);
+    if (nlon < 2 || nlat < 2) break;
+    size_t rec_size = 12 + 2 * (size_t)nlat;
+    rec.resize(rec_size);
+    tile->n_lat = nlat;
+    tile->n_lon = nlon;
+    tile->posts.assign((size_t)nlat * nlon, 0);
+    if (fseek(f, DTED_DATA_OFFSET, SEEK_SET)) break;
+    bool ok = true;
+    for (int j = 0; j < nlon && ok; j++) {
+      if (fread(rec.data(), 1, rec_size, f) != rec_size || rec[0] != 0xAA) {
+        ok = false;
+        break;
+      }
+      for (int i = 0; i < nlat; i++) {
+        unsigned v = ((unsigned)rec[8 + 2 * i] << 8) | rec[9 + 2 * i];
+        int e = (int)(v & 0x7fff);
+        if (v & 0x8000) e = -e; // signed magnitude
+        tile->posts[(size_t)i * nlon + j] = (int16_t)e;
+      }
+    }
+    if (!ok) break;
+    // `f64::from(header.origin_lat) as i16`: truncation (terrain/mod.rs:91-92)
+    *lat0 = sat_i16(olat);
+    *lon0 = sat_i16(olon);
+    rc = 0;
+  } while (0);
+  fclose(f);
+  if (rc) *msg = std::string("Could not buffer terrain file ") + path; // terrain/mod.rs:117
+  return rc;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------------
+extern "C" int atmrt_abi_version(void) { return ATMRT_ABI_VERSION; }
+
+extern "C" size_t atmrt_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(atmrt_params_t);
+    case 1: return sizeof(atmrt_atmosphere_t);
+    case 2: return sizeof(atmrt_object_t);
+    case 3: return sizeof(atmrt_result_t);
+    case 4: return sizeof(atmrt_device_planes_t);
+    case 5: return sizeof(atmrt_earth_model_t);
+    case 6: return sizeof(atmrt_position_t);
+    case 7: return sizeof(atmrt_frame_t);
+    default: return 0;
+  }
+}
+
+extern "C" const char* atmrt_last_error(const atmrt_ctx* ctx) {
+  if (ctx) return ctx->error.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  static thread_local std::string copy;
+  copy = g_create_error;
+  return copy.c_str();
+}
+
+static int create_fail(int code, const std::string& msg) {
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  g_create_error = msg;
+  return code;
+}
+
+extern "C" int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal) {
+  if (!out) return create_fail(ATMRT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return create_fail(ATMRT_ERR_NO_DEVICE,
+                       std::string("no HIP device available (") + hipGetErrorString(e) +
+                           "); this library has no CPU path");
+  if (device_ordinal < 0 || device_ordinal >= n)
+    return create_fail(ATMRT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess)
+    return create_fail(ATMRT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  atmrt_ctx* c = new atmrt_ctx();
+  c->device = device_ordinal;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess) {
+    std::string msg = std::string("stream/event creation: ") + hipGetErrorString(e);
+    atmrt_ctx_destroy(c);
+    return create_fail(ATMRT_ERR_HIP, msg);
+  }
+  for (hipEvent_t& ev : c->ev) {
+    if ((e = hipEventCreate(&ev)) != hipSuccess) {
+      std::string msg = std::string("hipEventCreate: ") + hipGetErrorString(e);
+      atmrt_ctx_destroy(c);
+      return create_fail(ATMRT_ERR_HIP, msg);
+    }
+  }
+  atmrt_params_default(&c->params);
+  atmrt_atmosphere_us76(&c->atm_def);
+  *out = c;
+  return ATMRT_OK;
+}
+
+extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  for (DevBuf* b : {&c->d_posts, &c->d_tiles, &c->d_cells, &c->d_xs, &c->d_alt, &c->d_colcalc, &c->d_prof, &c->d_pelev,
+                    &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
+                    &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_dense, &c->d_packed, &c->d_io})
+    b->release();
+  for (hipEvent_t ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+  if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  delete c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// terrain
+// ---------------------------------------------------------------------------------------------
+extern "C" int atmrt_terrain_clear(atmrt_ctx* c) {
+  if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  c->tiles.clear();
+  c->terrain_dirty = true;
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_terrain_add_tile(atmrt_ctx* c, int32_t lat0, int32_t lon0, int32_t n_lat, int32_t n_lon,
+                                      const int16_t* posts) {
+  if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!posts || n_lat < 2 || n_lon < 2 || n_lat > 65536 || n_lon > 65536)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "bad tile shape %d x %d", n_lat, n_lon);
+  if (lat0 < -90 || lat0 > 89 || lon0 < -360 || lon0 > 359)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "tile origin (%d, %d) out of range", lat0, lon0);
+  HostTile& t = c->tiles[{lat0, lon0}]; // HashMap::insert replaces (terrain/mod.rs:93-96)
+  t.n_lat = n_lat;
+  t.n_lon = n_lon;
+  t.posts.assign(posts, posts + (size_t)n_lat * n_lon);
+  c->terrain_dirty = true;
+  return ATMRT_OK;
+}
+
+// Terrain::from_folder, terrain/mod.rs:66-83
+extern "C" int atmrt_terrain_load_dir(atmrt_ctx* c, const char* path, int32_t* n_files) {
+  if (!c || !path) return ATMRT_ERR_INVALID_ARGUMENT;
+  DIR* d = opendir(path);
+  if (!d) return c->fail(ATMRT_ERR_IO, "Error opening the terrain data directory %s", path);
+  int files = 0;
+  while (struct dirent* ent = readdir(d)) {
+    if (!strcmp(ent->d_name, ".") || !strcmp(ent->d_name, "..")) continue;
+    std::string full = std::string(path) + "/" + ent->d_name;
+    HostTile t;
+    int lat0, lon0;
+    std::string msg;
+    int rc = read_dted(full.c_str(), &lat0, &lon0, &t, &msg);
+    if (rc) {
+      closedir(d);
+      return c->fail(rc, "%s", msg.c_str());
+    }
+    c->tiles[{lat0, lon0}] = std::move(t);
+    files++;
+  }
+  closedir(d);
+  c->terrain_dirty = true;
+  if (n_files) *n_files = files;
+  return ATMRT_OK;
+}
+
+// Upload the tile mosaic: all posts back to back + a dense (lat, lon) cell -> tile table.
+static int upload_terrain(atmrt_ctx* c) {
+  if (!c->terrain_dirty) return ATMRT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  TerrainView tv{};
+  if (c->tiles.empty()) {
+    tv.lat_min = tv.lon_min = 0;
+    tv.n_cells_lat = tv.n_cells_lon = 0;
+    c->tv = tv;
+    c->terrain_dirty = false;
+    return ATMRT_OK;
+  }
+  int lat_min = 1 << 30, lat_max = -(1 << 30), lon_min = 1 << 30, lon_max = -(1 << 30);
+  size_t total = 0;
+  for (auto& kv : c->tiles) {
+    lat_min = std::min(lat_min, kv.first.first);
+    lat_max = std::max(lat_max, kv.first.first);
+    lon_min = std::min(lon_min, kv.first.second);
+    lon_max = std::max(lon_max, kv.first.second);
+    total += kv.second.posts.size();
+  }
+  int ncl = lat_max - lat_min + 1, nco = lon_max - lon_min + 1;
+  std::vector<int32_t> cells((size_t)ncl * nco, -1);
+  std::vector<TileDesc> descs;
+  std::vector<int16_t> mosaic;
+  mosaic.reserve(total + 8);
+  for (auto& kv : c->tiles) {
+    TileDesc td;
+    td.offset = (int64_t)mosaic.size();
+    td.n_lat = kv.second.n_lat;
+    td.n_lon = kv.second.n_lon;
+    cells[(size_t)(kv.first.first - lat_min) * nco + (kv.first.second - lon_min)] = (int32_t)descs.size();
+    descs.push_back(td);
+    mosaic.insert(mosaic.end(), kv.second.posts.begin(), kv.second.posts.end());
+  }
+  HIP_TRY(c, c->d_posts.reserve(mosaic.size() * sizeof(int16_t)));
+  HIP_TRY(c, c->d_tiles.reserve(descs.size() * sizeof(TileDesc)));
+  HIP_TRY(c, c->d_cells.reserve(cells.size() * sizeof(int32_t)));
+  HIP_TRY(c, hipMemcpy(c->d_posts.ptr, mosaic.data(), mosaic.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_tiles.ptr, descs.data(), descs.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_cells.ptr, cells.data(), cells.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  tv.posts = c->d_posts.as<int16_t>();
+  tv.tiles = c->d_tiles.as<TileDesc>();
+  tv.cell_tile = c->d_cells.as<int32_t>();
+  tv.lat_min = lat_min;
+  tv.lon_min = lon_min;
+  tv.n_cells_lat = ncl;
+  tv.n_cells_lon = nco;
+  c->tv = tv;
+  c->terrain_dirty = false;
+  return ATMRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// configuration
+// ---------------------------------------------------------------------------------------------
+extern "C" void atmrt_params_default(atmrt_params_t* p) { // Config::default, params.rs:481-494
+  memset(p, 0, sizeof *p);
+  p->position.latitude = 0.0;
+  p->position.longitude = 0.0;
+  p->position.altitude_kind = ATMRT_ALT_RELATIVE; // params.rs:42-44
+  p->position.altitude = 1.0;
+  p->frame.direction = 0.0;
+  p->frame.tilt = 0.0;
+  p->frame.fov = 30.0;              // params.rs:156-158
+  p->frame.max_distance = 150000.0; // params.rs:160-162
+  p->earth.kind = ATMRT_EARTH_SPHERICAL;
+  p->earth.radius = 6371000.0; // params.rs:467-471
+  p->wavelength = 530e-9;      // params.rs:477-479
+  p->simulation_step = 50.0;   // params.rs:473-475
+  p->terrain_alpha = 1.0;      // params.rs:76-78
+  p->straight_rays = 0;
+  p->generator = ATMRT_GEN_FAST; // params.rs:427-429
+  p->width = 640;                // params.rs:419-425
+  p->height = 480;
+}
+
+extern "C" void atmrt_atmosphere_us76(atmrt_atmosphere_t* a) {
+  static const double alt[7] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0};
+  static const double lapse[7] = {-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002};
+  memset(a, 0, sizeof *a);
+  a->pressure_altitude = 0.0;
+  a->pressure = 101325.0;
+  a->temperature_altitude = 0.0;
+  a->temperature = 288.15;
+  a->n_layers = 7;
+  for (int k = 0; k < 7; k++) {
+    a->layer_altitude[k] = alt[k];
+    a->layer_gradient[k] = lapse[k];
+  }
+}
+
+extern "C" int atmrt_set_atmosphere(atmrt_ctx* c, const atmrt_atmosphere_t* a) {
+  if (!c || !a) return ATMRT_ERR_INVALID_ARGUMENT;
+  AtmTable t;
+  if (atm_compile(*a, c->params.wavelength, t))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere definition (n_layers=%d)", a->n_layers);
+  if (!(a->pressure > 0.0) || !(a->temperature > 0.0))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "pressure and temperature fixed points must be positive");
+  c->atm_def = *a;
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_set_params(atmrt_ctx* c, const atmrt_params_t* p) {
+  if (!c || !p) return ATMRT_ERR_INVALID_ARGUMENT;
+  Earth e;
+  if (earth_resolve(p->earth, e)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "unknown earth model kind %d", p->earth.kind);
+  if ((e.calc == 2 && !(e.calc_radius > 0.0)) || (e.calc == 3 && !(e.a > 0.0 && e.b > 0.0)))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "earth model radius / axes must be positive");
+  if (!(p->simulation_step > 0.0) || !std::isfinite(p->simulation_step))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "simulation_step must be positive");
+  if (!(p->frame.max_distance > 0.0) || !std::isfinite(p->frame.max_distance))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "max_distance must be positive and finite");
+  if (p->frame.max_distance / p->simulation_step > 4.0e6)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "max_distance / simulation_step exceeds 4e6 samples per ray");
+  if (p->width == 0 || p->height == 0 || p->width > 32767 || p->height > 32767) // i16 casts, fast.rs:116,122
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "width and height must be in 1..32767");
+  if (!(p->col_begin == 0 && p->col_end == 0) && !(p->col_begin < p->col_end && p->col_end <= p->width))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "column shard [%u, %u) outside width %u", p->col_begin, p->col_end, p->width);
+  if (p->generator < 0 || p->generator > 2) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "unknown generator %d", p->generator);
+  if (!(p->wavelength > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "wavelength must be positive");
+  if (p->simulation_step != c->params.simulation_step || p->frame.max_distance != c->params.frame.max_distance ||
+      !c->have_params)
+    c->xs_dirty = true;
+  c->params = *p;
+  c->earth = e;
+  c->have_params = true;
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_objects_set(atmrt_ctx* c, const atmrt_object_t* objects, size_t n) {
+  if (!c || (n && !objects)) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (n) return c->fail(ATMRT_ERR_UNSUPPORTED, "scene objects are not implemented on the device yet");
+  c->objects.clear();
+  return ATMRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame set-up
+// ---------------------------------------------------------------------------------------------
+static int prepare_frame(atmrt_ctx* c, Frame* out) {
+  if (!c->have_params) return c->fail(ATMRT_ERR_STATE, "atmrt_set_params has not been called");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = upload_terrain(c);
+  if (rc) return rc;
+  const atmrt_params_t& p = c->params;
+  if (atm_compile(c->atm_def, p.wavelength, c->atm)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere");
+  pinhole_init(p, c->pinhole);
+  if (c->xs_dirty) {
+    // distance table by repeated addition, exactly like `distance += step` (utils.rs:191-196) and the
+    // stepper's x; n_t = #{k: xs[k] < max}; the path cache gets one element more than the first k
+    // whose PREVIOUS x exceeds max (utils.rs:160-170)
+    c->xs.clear();
+    double d = 0.0;
+    int n_t = 0;
+    for (;;) {
+      c->xs.push_back(d);
+      if (d < p.frame.max_distance) n_t++;
+      size_t k = c->xs.size() - 1; // index of d
+      if (k >= 1 && c->xs[k - 1] > p.frame.max_distance) break;
+      d += p.simulation_step;
+      if (c->xs.size() > 5000000) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "distance table too long");
+    }
+    c->n_t = n_t;
+    c->n_path_cap = (int)c->xs.size();
+    HIP_TRY(c, c->d_xs.reserve(c->xs.size() * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(c->d_xs.ptr, c->xs.data(), c->xs.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->xs_dirty = false;
+  }
+  Frame f{};
+  f.p = p;
+  f.earth = c->earth;
+  f.atm = c->atm;
+  f.ph = c->pinhole;
+  f.tv = c->tv;
+  HIP_TRY(c, c->d_alt.reserve(sizeof(double)));
+  f.alt = c->d_alt.as<double>();
+  f.xs = c->d_xs.as<double>();
+  f.objects = nullptr;
+  f.textures = nullptr;
+  f.n_objects = 0;
+  f.n_t = c->n_t;
+  f.n_path_cap = c->n_path_cap;
+  f.c0 = (p.col_begin == 0 && p.col_end == 0) ? 0 : p.col_begin;
+  f.wl = (p.col_begin == 0 && p.col_end == 0) ? p.width : p.col_end - p.col_begin;
+  f.h = p.height;
+  f.opaque = (p.terrain_alpha == 1.0 && c->objects.empty()) ? 1 : 0;
+  *out = f;
+  return ATMRT_OK;
+}
+
+static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
+  size_t npx = (size_t)f.wl * f.h;
+  HIP_TRY(c, c->d_counters.reserve(4 * sizeof(uint64_t)));
+  HIP_TRY(c, c->d_hit_step.reserve(npx * sizeof(int32_t)));
+  HIP_TRY(c, c->d_hit_offset.reserve(npx * sizeof(uint64_t)));
+  HIP_TRY(c, c->d_scan_tmp.reserve((npx / 2048 + 2) * sizeof(uint64_t)));
+  if (f.p.generator != ATMRT_GEN_RECTILINEAR) {
+    HIP_TRY(c, c->d_colcalc.reserve((size_t)f.wl * sizeof(DirCalc)));
+    HIP_TRY(c, c->d_prof.reserve((size_t)f.n_t * f.wl * sizeof(double)));
+    HIP_TRY(c, c->d_pelev.reserve((size_t)f.h * f.n_path_cap * sizeof(double)));
+    HIP_TRY(c, c->d_plen.reserve((size_t)f.h * f.n_path_cap * sizeof(double)));
+    HIP_TRY(c, c->d_npath.reserve((size_t)f.h * sizeof(int32_t)));
+  }
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR) HIP_TRY(c, c->d_rect_rec.reserve(4 * npx * sizeof(double)));
+  ws->rect_rec = c->d_rect_rec.as<double>();
+  ws->alt = c->d_alt.as<double>();
+  ws->colcalc = c->d_colcalc.as<DirCalc>();
+  ws->prof = c->d_prof.as<double>();
+  ws->pelev = c->d_pelev.as<double>();
+  ws->plen = c->d_plen.as<double>();
+  ws->npath = c->d_npath.as<int32_t>();
+  ws->hit_step = c->d_hit_step.as<int32_t>();
+  ws->hit_offset = c->d_hit_offset.as<uint64_t>();
+  ws->scan_tmp = c->d_scan_tmp.as<uint64_t>();
+  ws->counters = c->d_counters.as<uint64_t>();
+  ws->list_step = nullptr;
+  ws->list_pixel = nullptr;
+  return ATMRT_OK;
+}
+
+static DensePlanes carve_dense(void* base, size_t npx) {
+  DensePlanes d;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    void* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  d.azimuth = (double*)take(npx * 8);
+  d.elevation_angle = (double*)take(npx * 8);
+  d.lat = (double*)take(npx * 8);
+  d.lon = (double*)take(npx * 8);
+  d.distance = (double*)take(npx * 8);
+  d.elevation = (double*)take(npx * 8);
+  d.path_length = (double*)take(npx * 8);
+  d.normal = (double*)take(npx * 24);
+  d.hit_count = (uint32_t*)take(npx * 4);
+  return d;
+}
+static size_t dense_bytes(size_t npx) { return 10 * (npx * 8 + 256) + npx * 4 + 512; }
+
+static PackedHits carve_packed(void* base, size_t n) {
+  PackedHits h;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    void* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  h.lat = (double*)take(n * 8);
+  h.lon = (double*)take(n * 8);
+  h.distance = (double*)take(n * 8);
+  h.elevation = (double*)take(n * 8);
+  h.path_length = (double*)take(n * 8);
+  h.normal = (double*)take(n * 24);
+  h.rgba = (double*)take(n * 32);
+  h.color_tag = (uint32_t*)take(n * 4);
+  return h;
+}
+static size_t packed_bytes(size_t n) { return n * (5 * 8 + 24 + 32 + 4) + 8 * 256 + 256; }
+
+// Runs the generator named in params.  `dense` must be device memory.  When `want_packed`, the
+// packed trace points are left in c->d_packed (n_hits of them).
+static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlanes& dense, bool want_packed,
+                         PackedHits* packed_out, uint64_t* n_hits_out, uint64_t* ray_steps_out, double* ms_out) {
+  if (f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR)
+    return c->fail(ATMRT_ERR_UNSUPPORTED, "InterpolatingRectilinear is not implemented on the device yet");
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipEventRecord(c->ev_t0, s));
+  HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint64_t), s));
+  launch_resolve(f, ws, nullptr, s);
+  // phase events: [0..1] profile, [2..3] paths (stream2), [4..5] intersect / march, [5..6] finalize, [7..8] pack
+  hipEvent_t* ev = c->ev;
+  const bool fast = f.p.generator == ATMRT_GEN_FAST;
+  if (fast) {
+    launch_fast_caches(f, ws, s, c->stream2, c->ev_fork, c->ev_join, ev);
+    HIP_TRY(c, hipEventRecord(ev[4], s));
+    launch_fast_intersect(f, ws, dense, s);
+    HIP_TRY(c, hipEventRecord(ev[5], s));
+    if (f.opaque) launch_fast_finalize(f, ws, dense, s);
+    HIP_TRY(c, hipEventRecord(ev[6], s));
+  } else {
+    HIP_TRY(c, hipEventRecord(ev[4], s));
+    launch_rect_march(f, ws, dense, s, ev[5]);
+    HIP_TRY(c, hipEventRecord(ev[6], s));
+  }
+  HIP_TRY(c, hipEventRecord(ev[7], s));
+  uint64_t counters[4] = {0, 0, 0, 0};
+  PackedHits packed{};
+  if (want_packed || !f.opaque) {
+    launch_scan_counts(f, ws, dense.hit_count, s);
+    HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    uint64_t n_hits = counters[1];
+    HIP_TRY(c, c->d_packed.reserve(packed_bytes(n_hits)));
+    packed = carve_packed(c->d_packed.ptr, n_hits);
+    if (f.opaque) {
+      launch_pack_first_hits(f, ws, dense, packed, s);
+    } else {
+      HIP_TRY(c, c->d_list_step.reserve((n_hits + 1) * sizeof(uint32_t)));
+      HIP_TRY(c, c->d_list_pixel.reserve((n_hits + 1) * sizeof(uint32_t)));
+      ws.list_step = c->d_list_step.as<uint32_t>();
+      ws.list_pixel = c->d_list_pixel.as<uint32_t>();
+      if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
+        HIP_TRY(c, c->d_rect_rec.reserve(4 * (n_hits + 1) * sizeof(double)));
+        ws.rect_rec = c->d_rect_rec.as<double>();
+        launch_multi_fill(f, ws, n_hits, dense, packed, s);
+      } else {
+        launch_multi_fill_fast(f, ws, n_hits, dense, packed, s);
+      }
+    }
+    *n_hits_out = n_hits;
+  }
+  HIP_TRY(c, hipEventRecord(ev[8], s));
+  HIP_TRY(c, hipEventRecord(c->ev_t1, s));
+  HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+  {
+    atmrt_timings_t t{};
+    float v = 0.f;
+    t.total_ms = ms;
+    if (fast) {
+      HIP_TRY(c, hipEventElapsedTime(&v, ev[0], ev[1]));
+      t.profile_ms = v;
+      HIP_TRY(c, hipEventElapsedTime(&v, ev[2], ev[3]));
+      t.paths_ms = v;
+      HIP_TRY(c, hipEventElapsedTime(&v, ev[4], ev[5]));
+      t.intersect_ms = v;
+    } else {
+      HIP_TRY(c, hipEventElapsedTime(&v, ev[4], ev[5]));
+      t.march_ms = v;
+    }
+    HIP_TRY(c, hipEventElapsedTime(&v, ev[5], ev[6]));
+    t.finalize_ms = v;
+    HIP_TRY(c, hipEventElapsedTime(&v, ev[7], ev[8]));
+    t.pack_ms = v;
+    t.ray_steps = counters[0];
+    t.n_hits = counters[1];
+    c->timings = t;
+  }
+  if (ms_out) *ms_out = ms;
+  if (ray_steps_out) *ray_steps_out = counters[0];
+  if (packed_out) *packed_out = packed;
+  return ATMRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the path
+// ---------------------------------------------------------------------------------------------
+extern "C" void atmrt_result_free(atmrt_result_t* r) {
+  if (!r) return;
+  free(r->azimuth);
+  free(r->elevation_angle);
+  free(r->hit_count);
+  free(r->hit_offset);
+  free(r->lat);
+  free(r->lon);
+  free(r->distance);
+  free(r->elevation);
+  free(r->path_length);
+  free(r->normal);
+  free(r->color_tag);
+  free(r->rgba);
+  memset(r, 0, sizeof *r);
+}
+
+extern "C" int atmrt_generate(atmrt_ctx* c, atmrt_result_t* out) {
+  if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
+  memset(out, 0, sizeof *out);
+  Frame f;
+  int rc = prepare_frame(c, &f);
+  if (rc) return rc;
+  Workspace ws{};
+  if ((rc = prepare_workspace(c, f, &ws))) return rc;
+  size_t npx = (size_t)f.wl * f.h;
+  HIP_TRY(c, c->d_dense.reserve(dense_bytes(npx)));
+  DensePlanes dense = carve_dense(c->d_dense.ptr, npx);
+  PackedHits packed{};
+  uint64_t n_hits = 0, steps = 0;
+  double ms = 0;
+  if ((rc = run_generator(c, f, ws, dense, true, &packed, &n_hits, &steps, &ms))) return rc;
+
+  out->width = (uint32_t)f.wl;
+  out->height = (uint32_t)f.h;
+  out->n_pixels = npx;
+  out->n_hits = n_hits;
+  out->ray_steps = steps;
+  out->device_ms = ms;
+  size_t nh = n_hits ? n_hits : 1;
+  out->azimuth = (double*)malloc(npx * 8);
+  out->elevation_angle = (double*)malloc(npx * 8);
+  out->hit_count = (uint32_t*)malloc(npx * 4);
+  out->hit_offset = (uint64_t*)malloc(npx * 8);
+  out->lat = (double*)malloc(nh * 8);
+  out->lon = (double*)malloc(nh * 8);
+  out->distance = (double*)malloc(nh * 8);
+  out->elevation = (double*)malloc(nh * 8);
+  out->path_length = (double*)malloc(nh * 8);
+  out->normal = (double*)malloc(nh * 24);
+  out->color_tag = (uint32_t*)malloc(nh * 4);
+  out->rgba = (double*)malloc(nh * 32);
+  if (!out->azimuth || !out->elevation_angle || !out->hit_count || !out->hit_offset || !out->lat || !out->lon ||
+      !out->distance || !out->elevation || !out->path_length || !out->normal || !out->color_tag || !out->rgba) {
+    atmrt_result_free(out);
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "out of host memory for %zu pixels / %llu hits", npx,
+                   (unsigned long long)n_hits);
+  }
+  HIP_TRY(c, hipMemcpy(out->azimuth, dense.azimuth, npx * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out->elevation_angle, dense.elevation_angle, npx * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out->hit_count, dense.hit_count, npx * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out->hit_offset, ws.hit_offset, npx * 8, hipMemcpyDeviceToHost));
+  if (n_hits) {
+    HIP_TRY(c, hipMemcpy(out->lat, packed.lat, n_hits * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->lon, packed.lon, n_hits * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->distance, packed.distance, n_hits * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->elevation, packed.elevation, n_hits * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->path_length, packed.path_length, n_hits * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->normal, packed.normal, n_hits * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->color_tag, packed.color_tag, n_hits * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->rgba, packed.rgba, n_hits * 32, hipMemcpyDeviceToHost));
+  }
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_generate_device(atmrt_ctx* c, const atmrt_device_planes_t* planes, uint64_t* ray_steps,
+                                     double* device_ms) {
+  if (!c || !planes) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!planes->azimuth || !planes->elevation_angle || !planes->hit_count || !planes->lat || !planes->lon ||
+      !planes->distance || !planes->elevation || !planes->path_length || !planes->normal)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "every plane pointer must be a device allocation");
+  Frame f;
+  int rc = prepare_frame(c, &f);
+  if (rc) return rc;
+  Workspace ws{};
+  if ((rc = prepare_workspace(c, f, &ws))) return rc;
+  DensePlanes dense;
+  dense.azimuth = planes->azimuth;
+  dense.elevation_angle = planes->elevation_angle;
+  dense.hit_count = planes->hit_count;
+  dense.lat = planes->lat;
+  dense.lon = planes->lon;
+  dense.distance = planes->distance;
+  dense.elevation = planes->elevation;
+  dense.path_length = planes->path_length;
+  dense.normal = planes->normal;
+  uint64_t n_hits = 0;
+  return run_generator(c, f, ws, dense, false, nullptr, &n_hits, ray_steps, device_ms);
+}
+
+extern "C" int atmrt_last_timings(atmrt_ctx* c, atmrt_timings_t* out) {
+  if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
+  *out = c->timings;
+  return ATMRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// harnesses: host arrays in, host arrays out (staged through one device buffer)
+// ---------------------------------------------------------------------------------------------
+static int harness_frame(atmrt_ctx* c, Frame* f) {
+  if (!c->have_params) {
+    atmrt_params_t p;
+    atmrt_params_default(&p);
+    int rc = atmrt_set_params(c, &p);
+    if (rc) return rc;
+  }
+  return prepare_frame(c, f);
+}
+
+extern "C" int atmrt_terrain_get_elev(atmrt_ctx* c, size_t n, const double* lat, const double* lon, double* elev,
+                                      uint8_t* valid) {
+  if (!c || (n && (!lat || !lon || !elev || !valid))) return ATMRT_ERR_INVALID_ARGUMENT;
+  Frame f;
+  int rc = harness_frame(c, &f);
+  if (rc) return rc;
+  if (!n) return ATMRT_OK;
+  HIP_TRY(c, c->d_io.reserve(n * 25 + 1024));
+  double* d_lat = c->d_io.as<double>();
+  double* d_lon = d_lat + n;
+  double* d_elev = d_lon + n;
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_elev + n);
+  HIP_TRY(c, hipMemcpyAsync(d_lat, lat, n * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_lon, lon, n * 8, hipMemcpyHostToDevice, c->stream));
+  launch_get_elev(f, n, d_lat, d_lon, d_elev, d_valid, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(elev, d_elev, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_ray_paths(atmrt_ctx* c, double h0, size_t n_angles, const double* angles_deg, int32_t straight,
+                               double step, size_t n_steps, double* x, double* h) {
+  if (!c || (n_angles && (!angles_deg || !x || !h))) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!(step > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "step must be positive"); // ray_path.rs:53
+  if (n_steps > 50000000) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "too many steps");
+  Frame f;
+  int rc = harness_frame(c, &f);
+  if (rc) return rc;
+  if (!n_angles) return ATMRT_OK;
+  size_t m = n_angles * (n_steps + 1);
+  HIP_TRY(c, c->d_io.reserve((n_angles + 2 * m) * 8));
+  double* d_ang = c->d_io.as<double>();
+  double* d_x = d_ang + n_angles;
+  double* d_h = d_x + m;
+  HIP_TRY(c, hipMemcpyAsync(d_ang, angles_deg, n_angles * 8, hipMemcpyHostToDevice, c->stream));
+  launch_ray_paths(f, h0, n_angles, d_ang, straight, step, n_steps, d_x, d_h, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(x, d_x, m * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h, d_h, m * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_atmosphere_sample(atmrt_ctx* c, size_t n, const double* altitude, double* temperature,
+                                       double* pressure, double* n_index, double* dn_dh) {
+  if (!c || (n && (!altitude || !temperature || !pressure || !n_index || !dn_dh))) return ATMRT_ERR_INVALID_ARGUMENT;
+  Frame f;
+  int rc = harness_frame(c, &f);
+  if (rc) return rc;
+  if (!n) return ATMRT_OK;
+  HIP_TRY(c, c->d_io.reserve(5 * n * 8));
+  double* d = c->d_io.as<double>();
+  HIP_TRY(c, hipMemcpyAsync(d, altitude, n * 8, hipMemcpyHostToDevice, c->stream));
+  launch_atm_sample(f, n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(temperature, d + n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(pressure, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(n_index, d + 3 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(dn_dh, d + 4 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_coords_at_dist(atmrt_ctx* c, double lat0, double lon0, double dir_deg, size_t n,
+                                    const double* dist, double* lat, double* lon) {
+  if (!c || (n && (!dist || !lat || !lon))) return ATMRT_ERR_INVALID_ARGUMENT;
+  Frame f;
+  int rc = harness_frame(c, &f);
+  if (rc) return rc;
+  if (!n) return ATMRT_OK;
+  HIP_TRY(c, c->d_io.reserve(3 * n * 8));
+  double* d = c->d_io.as<double>();
+  HIP_TRY(c, hipMemcpyAsync(d, dist, n * 8, hipMemcpyHostToDevice, c->stream));
+  launch_coords_at_dist(f, lat0, lon0, dir_deg, n, d, d + n, d + 2 * n, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(lat, d + n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(lon, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return ATMRT_OK;
+}

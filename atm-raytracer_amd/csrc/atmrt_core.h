@@ -1,0 +1,592 @@
+// atmrt_core.h — f64 numerics of the ray-marching path, shared by the HIP kernels and by the
+// library's host-side set-up code (atmosphere table, distance table).  Everything is
+// __host__ __device__ and built on detmath.h so that host set-up and device kernels agree to the
+// bit.  Reference citations are relative to /root/reference.
+//
+// Compile with -ffp-contract=off: the CPU checker (oracle/) executes the same operation sequence
+// without FMA contraction and results are compared bit-for-bit.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ATMRT_HD __host__ __device__ inline __attribute__((always_inline))
+#define DM_FN __host__ __device__ static inline __attribute__((always_inline))
+#else
+#define ATMRT_HD inline
+#endif
+#include "detmath.h"
+
+#include "../../include/atmrt.h"
+
+namespace atmrt {
+
+struct Vec3 {
+  double x, y, z;
+};
+ATMRT_HD Vec3 v3(double x, double y, double z) { return Vec3{x, y, z}; }
+ATMRT_HD Vec3 operator+(Vec3 a, Vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+ATMRT_HD Vec3 operator-(Vec3 a, Vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+ATMRT_HD Vec3 operator-(Vec3 a) { return v3(-a.x, -a.y, -a.z); }
+ATMRT_HD Vec3 operator*(Vec3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+ATMRT_HD Vec3 operator/(Vec3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+ATMRT_HD double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Atmosphere + refractive index (crate atm-refraction 0.6, source absent: published models —
+// US Standard Atmosphere 1976 layers, hydrostatic ideal gas, Ciddor 1996 dry air).
+// ---------------------------------------------------------------------------------------------
+
+struct AtmTable {
+  int32_t n;
+  int32_t _pad;
+  double hb[ATMRT_MAX_ATM_LAYERS];    // reference altitude of layer k
+  double tb[ATMRT_MAX_ATM_LAYERS];    // temperature at hb
+  double pb[ATMRT_MAX_ATM_LAYERS];    // pressure at hb
+  double lapse[ATMRT_MAX_ATM_LAYERS]; // dT/dh
+  double from[ATMRT_MAX_ATM_LAYERS];  // layer k >= 1 applies for h >= from[k]
+  double expo[ATMRT_MAX_ATM_LAYERS];  // lapse != 0: -g0 M/(R lapse); lapse == 0: -g0 M/(R tb)
+  double k_refr;                      // (n - 1) = k_refr * (p/T) / Z
+};
+
+ATMRT_HD int atm_layer(const AtmTable& a, double h) {
+  for (int k = a.n - 1; k >= 1; k--)
+    if (h >= a.from[k]) return k;
+  return 0;
+}
+
+ATMRT_HD double atm_pressure_ratio(const AtmTable& a, int k, double h) {
+  if (a.lapse[k] != 0.0) {
+    double t = a.tb[k] + a.lapse[k] * (h - a.hb[k]);
+    return dm_pow(t / a.tb[k], a.expo[k]);
+  }
+  return dm_exp(a.expo[k] * (h - a.hb[k]));
+}
+
+// Atmosphere::from_def (params.rs:514): chain temperature and pressure outwards from the fixed points.
+ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTable& out) {
+  const double gmr = 9.80665 * 0.0289644 / 8.31432;
+  int n = def.n_layers;
+  if (n < 1 || n > ATMRT_MAX_ATM_LAYERS) return -1;
+  out.n = n;
+  out._pad = 0;
+  for (int k = 0; k < ATMRT_MAX_ATM_LAYERS; k++) {
+    out.hb[k] = out.tb[k] = out.pb[k] = out.lapse[k] = out.from[k] = out.expo[k] = 0.0;
+  }
+  for (int k = 0; k < n; k++) {
+    out.lapse[k] = def.layer_gradient[k];
+    out.from[k] = k == 0 ? 0.0 : def.layer_altitude[k];
+    if (k >= 2 && !(out.from[k] > out.from[k - 1])) return -1;
+  }
+  int jt = 0;
+  for (int k = n - 1; k >= 1; k--)
+    if (def.temperature_altitude >= out.from[k]) { jt = k; break; }
+  out.hb[jt] = jt == 0 ? def.temperature_altitude : out.from[jt];
+  out.tb[jt] = def.temperature - out.lapse[jt] * (def.temperature_altitude - out.hb[jt]);
+  for (int k = jt + 1; k < n; k++) {
+    out.hb[k] = out.from[k];
+    out.tb[k] = out.tb[k - 1] + out.lapse[k - 1] * (out.from[k] - out.hb[k - 1]);
+  }
+  for (int k = jt - 1; k >= 0; k--) {
+    out.hb[k] = k == 0 ? out.from[1] : out.from[k];
+    out.tb[k] = out.tb[k + 1] - out.lapse[k] * (out.from[k + 1] - out.hb[k]);
+  }
+  for (int k = 0; k < n; k++) out.expo[k] = out.lapse[k] != 0.0 ? -gmr / out.lapse[k] : -gmr / out.tb[k];
+  int jp = 0;
+  for (int k = n - 1; k >= 1; k--)
+    if (def.pressure_altitude >= out.from[k]) { jp = k; break; }
+  out.pb[jp] = def.pressure / atm_pressure_ratio(out, jp, def.pressure_altitude);
+  for (int k = jp + 1; k < n; k++) out.pb[k] = out.pb[k - 1] * atm_pressure_ratio(out, k - 1, out.from[k]);
+  for (int k = jp - 1; k >= 0; k--) out.pb[k] = out.pb[k + 1] / atm_pressure_ratio(out, k, out.from[k + 1]);
+  {
+    const double k0 = 238.0185, k1 = 5792105.0, k2 = 57.362, k3 = 167917.0;
+    const double xco2 = 450.0, pr1 = 101325.0, tr1 = 288.15, za = 0.9995922115, r = 8.314472;
+    double lam_um = wavelength * 1.0e6;
+    double s = 1.0 / (lam_um * lam_um);
+    double ras = 1.0e-8 * (k1 / (k0 - s) + k3 / (k2 - s));
+    double raxs = ras * (1.0 + 5.34e-7 * (xco2 - 450.0));
+    double ma = 0.0289635 + 1.2011e-8 * (xco2 - 400.0);
+    double rho_axs = pr1 * ma / (za * r * tr1);
+    out.k_refr = raxs / rho_axs * ma / r;
+  }
+  return 0;
+}
+
+ATMRT_HD double atm_temperature(const AtmTable& a, double h) {
+  int k = atm_layer(a, h);
+  return a.tb[k] + a.lapse[k] * (h - a.hb[k]);
+}
+ATMRT_HD double atm_pressure(const AtmTable& a, double h) {
+  int k = atm_layer(a, h);
+  return a.pb[k] * atm_pressure_ratio(a, k, h);
+}
+
+// Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).
+ATMRT_HD double refr_n(const AtmTable& a, double h) {
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
+  int k = atm_layer(a, h);
+  double temp = a.tb[k] + a.lapse[k] * (h - a.hb[k]);
+  double p = a.pb[k] * atm_pressure_ratio(a, k, h);
+  double t = temp - 273.15;
+  double pt = p / temp;
+  double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
+  return 1.0 + a.k_refr * pt / z;
+}
+ATMRT_HD double refr_dn(const AtmTable& a, double h) {
+  const double eps = 0.01;
+  double n1 = refr_n(a, h - eps);
+  double n2 = refr_n(a, h + eps);
+  return (n2 - n1) / (2.0 * eps);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Earth model + directional calculators (src/utils/earth_model/{mod,directional_calc}.rs)
+// ---------------------------------------------------------------------------------------------
+
+constexpr double DEGREE_DISTANCE = 10000000.0 / 90.0; // earth_model/mod.rs:12
+constexpr double EARTH_R = 6371000.0;                 // :14
+constexpr double WGS84_A = 6378137.0;                 // :15
+constexpr double WGS84_B = 6356752.314245;            // :16
+
+// EarthModel resolved once on the host into the four behaviours the path needs.
+struct Earth {
+  int32_t calc;       // 0 AzEq, 1 FlDs, 2 Spherical, 3 Ellipsoid     (coords_at_dist_calc, mod.rs:114-145)
+  int32_t flat_dirs;  // world_directions / as_cartesian flat family  (mod.rs:31-57,59-93)
+  int32_t cart;       // 0 flat, 1 spherical(cart_radius), 2 ellipsoid(a,b)
+  int32_t spherical;  // EarthShape::Spherical{shape_radius} vs Flat  (to_shape, mod.rs:95-112)
+  double calc_radius; // SphericalCalc radius
+  double cart_radius;
+  double a, b;
+  double shape_radius;
+};
+
+ATMRT_HD int earth_resolve(const atmrt_earth_model_t& m, Earth& e) {
+  e.calc_radius = e.cart_radius = e.a = e.b = e.shape_radius = 0.0;
+  switch (m.kind) {
+    case ATMRT_EARTH_SIMPLE_SPHERE:
+      e.calc = 2; e.flat_dirs = 0; e.cart = 1; e.spherical = 1;
+      e.calc_radius = e.cart_radius = e.shape_radius = EARTH_R;
+      return 0;
+    case ATMRT_EARTH_SPHERICAL:
+      e.calc = 2; e.flat_dirs = 0; e.cart = 1; e.spherical = 1;
+      e.calc_radius = e.cart_radius = e.shape_radius = m.radius;
+      return 0;
+    case ATMRT_EARTH_ELLIPSOID:
+    case ATMRT_EARTH_WGS84:
+      e.calc = 3; e.flat_dirs = 0; e.cart = 2; e.spherical = 1;
+      e.a = m.kind == ATMRT_EARTH_WGS84 ? WGS84_A : m.a;
+      e.b = m.kind == ATMRT_EARTH_WGS84 ? WGS84_B : m.b;
+      e.shape_radius = (2.0 * e.a + e.b) / 3.0;
+      return 0;
+    case ATMRT_EARTH_AZIMUTHAL_EQUIDISTANT:
+      e.calc = 0; e.flat_dirs = 1; e.cart = 0; e.spherical = 0;
+      return 0;
+    case ATMRT_EARTH_FLAT_DISTORTED:
+      e.calc = 1; e.flat_dirs = 1; e.cart = 0; e.spherical = 0;
+      return 0;
+    case ATMRT_EARTH_OBSERVER_AE:
+    case ATMRT_EARTH_SIMPLE_OBSERVER_AE:
+      e.calc = 2; e.flat_dirs = 1; e.cart = 0; e.spherical = 0;
+      e.calc_radius = m.kind == ATMRT_EARTH_OBSERVER_AE ? m.radius : EARTH_R;
+      return 0;
+    default: return -1;
+  }
+}
+
+// spherical_directions, mod.rs:155-172
+ATMRT_HD void spherical_directions(double lat, double lon, Vec3& dirn, Vec3& dire, Vec3& dirup) {
+  double sinlon, coslon, sinlat, coslat;
+  dm_sincos(dm_to_radians(lon), &sinlon, &coslon);
+  dm_sincos(dm_to_radians(lat), &sinlat, &coslat);
+  dirup = v3(coslat * coslon, coslat * sinlon, sinlat);
+  dirn = v3(-sinlat * coslon, -sinlat * sinlon, coslat);
+  dire = v3(-sinlon, coslon, 0.0);
+}
+
+// EarthModel::world_directions, mod.rs:31-57
+ATMRT_HD void world_directions(const Earth& e, double lat, double lon, Vec3& n, Vec3& ea, Vec3& up) {
+  if (e.flat_dirs) {
+    double sinlon, coslon;
+    dm_sincos(dm_to_radians(lon), &sinlon, &coslon);
+    n = v3(-coslon, -sinlon, 0.0);
+    ea = v3(-sinlon, coslon, 0.0);
+    up = v3(0.0, 0.0, 1.0);
+  } else {
+    spherical_directions(lat, lon, n, ea, up);
+  }
+}
+
+// EarthModel::as_cartesian, mod.rs:59-93 (+ spherical_to_cartesian :148-153)
+ATMRT_HD Vec3 as_cartesian(const Earth& e, double lat, double lon, double elev) {
+  if (e.cart == 1) {
+    double r = e.cart_radius + elev;
+    double sl, cl, so, co;
+    dm_sincos(dm_to_radians(lat), &sl, &cl);
+    dm_sincos(dm_to_radians(lon), &so, &co);
+    return v3(r * cl * co, r * cl * so, r * sl);
+  }
+  if (e.cart == 2) {
+    double e2 = 1.0 - (e.b * e.b) / (e.a * e.a);
+    double sl, cl, so, co;
+    dm_sincos(dm_to_radians(lat), &sl, &cl);
+    dm_sincos(dm_to_radians(lon), &so, &co);
+    double n = e.a / dm_sqrt(1.0 - e2 * (sl * sl));
+    return v3((n + elev) * cl * co, (n + elev) * cl * so, (n * (1.0 - e2) + elev) * sl);
+  }
+  double r = (90.0 - lat) * DEGREE_DISTANCE;
+  double so, co;
+  dm_sincos(dm_to_radians(lon), &so, &co);
+  return v3(r * co, r * so, elev);
+}
+
+// Box<dyn DirectionalCalc> flattened: one POD for the four implementors.
+struct DirCalc {
+  // Spherical: pos = unit up vector at start, dir = unit tangent.  AzEq: pos cartesian, dir = dir_v.
+  Vec3 pos, dir;
+  // FlDs: p0 = start lat, p1 = start lon, p2 = cos(dir), p3 = sin(dir), p4 = cos(start lat)
+  // Ellipsoid: p0..p9 = b, f, red_lat, lon, az1, alfa, sig1, cap_a, cap_b, cap_c
+  double p[10];
+};
+
+// EarthModel::coords_at_dist_calc, mod.rs:114-145 and the ::new of each calculator
+ATMRT_HD void dircalc_new(const Earth& e, double lat, double lon, double dir, DirCalc& c) {
+  for (int i = 0; i < 10; i++) c.p[i] = 0.0;
+  c.pos = c.dir = v3(0.0, 0.0, 0.0);
+  if (e.calc == 2) { // SphericalCalc::new, directional_calc.rs:56-69
+    Vec3 dirn, dire, pos;
+    spherical_directions(lat, lon, dirn, dire, pos);
+    double sindir, cosdir;
+    dm_sincos(dm_to_radians(dir), &sindir, &cosdir);
+    c.pos = pos;
+    c.dir = dirn * cosdir + dire * sindir;
+  } else if (e.calc == 0) { // AzEqCalc, mod.rs:116-125
+    Vec3 vn, ve, vu;
+    c.pos = as_cartesian(e, lat, lon, 0.0);
+    world_directions(e, lat, lon, vn, ve, vu);
+    double s, co;
+    dm_sincos(dm_to_radians(dir), &s, &co);
+    c.dir = vn * co + ve * s;
+  } else if (e.calc == 1) { // FlDsCalc::new, directional_calc.rs:35-39
+    c.p[0] = lat;
+    c.p[1] = lon;
+    dm_sincos(dm_to_radians(dir), &c.p[3], &c.p[2]);
+    c.p[4] = dm_cos(dm_to_radians(lat));
+  } else { // EllipsoidCalc::new, directional_calc.rs:103-131
+    double a = e.a, b = e.b;
+    double la = dm_to_radians(lat), lo = dm_to_radians(lon), az1 = dm_to_radians(dir);
+    double f = (a - b) / a;
+    double red_lat = dm_atan((1.0 - f) * dm_tan(la));
+    double sig1 = dm_atan(dm_tan(red_lat) / dm_cos(az1));
+    double alfa = dm_asin(dm_cos(red_lat) * dm_sin(az1));
+    double ca = dm_cos(alfa);
+    double u2 = ca * ca * (a * a - b * b) / (b * b);
+    c.p[0] = b;
+    c.p[1] = f;
+    c.p[2] = red_lat;
+    c.p[3] = lo;
+    c.p[4] = az1;
+    c.p[5] = alfa;
+    c.p[6] = sig1;
+    c.p[7] = 1.0 + u2 / 256.0 * (64.0 + u2 * (-12.0 + 5.0 * u2));
+    c.p[8] = u2 / 512.0 * (128.0 + u2 * (-64.0 + 37.0 * u2));
+    c.p[9] = f / 16.0 * (ca * ca) * (4.0 + f * (4.0 - 3.0 * (ca * ca)));
+  }
+}
+
+// DirectionalCalc::coords_at_dist
+ATMRT_HD void coords_at_dist(const Earth& e, const DirCalc& c, double dist, double& lat, double& lon) {
+  if (e.calc == 2) { // SphericalCalc, directional_calc.rs:72-85
+    double ang = dist / e.calc_radius;
+    double sinang, cosang;
+    dm_sincos(ang, &sinang, &cosang);
+    double fx = c.pos.x * cosang + c.dir.x * sinang;
+    double fy = c.pos.y * cosang + c.dir.y * sinang;
+    double fz = c.pos.z * cosang + c.dir.z * sinang;
+    lat = dm_to_degrees(dm_asin(fz));
+    lon = dm_to_degrees(dm_atan2(fy, fx));
+  } else if (e.calc == 0) { // AzEqCalc, directional_calc.rs:20-28
+    double px = c.pos.x + c.dir.x * dist, py = c.pos.y + c.dir.y * dist;
+    lon = dm_to_degrees(dm_atan2(py, px));
+    double r = dm_sqrt(px * px + py * py);
+    lat = 90.0 - r / DEGREE_DISTANCE;
+  } else if (e.calc == 1) { // FlDsCalc, directional_calc.rs:41-48
+    double d_lat = c.p[2] * dist / DEGREE_DISTANCE;
+    double d_lon = c.p[3] * dist / DEGREE_DISTANCE / c.p[4];
+    lat = c.p[0] + d_lat;
+    lon = c.p[1] + d_lon;
+  } else { // EllipsoidCalc (Vincenty direct), directional_calc.rs:135-185
+    const double b = c.p[0], f = c.p[1], red_lat = c.p[2], lon0 = c.p[3], az1 = c.p[4], alfa = c.p[5],
+                 sig1 = c.p[6], cap_a = c.p[7], cap_b = c.p[8], cap_c = c.p[9];
+    double sig = dist / b / cap_a, sigm, cs;
+    // bounded (the reference loops unbounded and would spin on NaN); 64 is never reached for finite input
+    for (int it = 0; it < 64; it++) {
+      sigm = 2.0 * sig1 + sig;
+      cs = dm_cos(sigm);
+      double dsig = cap_b * dm_sin(sig) * (cs + cap_b / 4.0 * dm_cos(sig) * (-1.0 + 2.0 * (cs * cs)));
+      double new_sig = dist / b / cap_a + dsig;
+      dsig = dm_fabs(new_sig - sig);
+      sig = new_sig;
+      if (dsig < 1e-10) break;
+    }
+    sigm = 2.0 * sig1 + sig;
+    double srl, crl, ss, csg, sa, saz, caz;
+    dm_sincos(red_lat, &srl, &crl);
+    dm_sincos(sig, &ss, &csg);
+    dm_sincos(az1, &saz, &caz);
+    sa = dm_sin(alfa);
+    double t = srl * ss - crl * csg * caz;
+    double lat2 = dm_atan((srl * csg + crl * ss * caz) / ((1.0 - f) * dm_sqrt(sa * sa + t * t)));
+    double lambda = dm_atan(ss * saz / (crl * csg - srl * ss * caz));
+    cs = dm_cos(sigm);
+    double dl = lambda - (1.0 - cap_c) * f * sa * (sig + cap_c * ss * (cs + cap_c * csg * (-1.0 + 2.0 * (cs * cs))));
+    lat = dm_to_degrees(lat2);
+    lon = dm_to_degrees(lon0 + dl);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Terrain mosaic in HBM + bilinear sampler (src/terrain/mod.rs:120-126, tile.rs:28-30; sampler
+// modelled on terrain/geotiff.rs:61-100 because crate dted 0.2 is absent)
+// ---------------------------------------------------------------------------------------------
+
+struct TileDesc {
+  int64_t offset; // first post of the tile in the mosaic buffer
+  int32_t n_lat, n_lon;
+};
+
+struct TerrainView {
+  const int16_t* posts;     // all tiles back to back, each [n_lat][n_lon] south->north, west->east
+  const TileDesc* tiles;
+  const int32_t* cell_tile; // [n_cells_lat][n_cells_lon] -> tile slot or -1
+  int32_t lat_min, lon_min, n_cells_lat, n_cells_lon;
+};
+
+// Rust `f as i16` / `f as usize` (saturating, NaN -> 0)
+ATMRT_HD int sat_i16(double f) {
+  if (f != f) return 0;
+  if (f <= -32768.0) return -32768;
+  if (f >= 32767.0) return 32767;
+  return (int)f;
+}
+ATMRT_HD int sat_index(double f) {
+  if (f != f || f <= 0.0) return 0;
+  if (f >= 2147483647.0) return 2147483647;
+  return (int)f;
+}
+
+// Terrain::get_elev: returns false for None.  4 int16 posts = 8 B of HBM traffic per lookup.
+ATMRT_HD bool terrain_get_elev(const TerrainView& tv, double latitude, double longitude, double& elev) {
+  int lat = sat_i16(dm_floor(latitude));
+  int lon = sat_i16(dm_floor(longitude));
+  int ci = lat - tv.lat_min, cj = lon - tv.lon_min;
+  if (ci < 0 || cj < 0 || ci >= tv.n_cells_lat || cj >= tv.n_cells_lon) return false;
+  int slot = tv.cell_tile[ci * tv.n_cells_lon + cj];
+  if (slot < 0) return false;
+  const TileDesc td = tv.tiles[slot];
+  double min_lat = (double)lat, min_lon = (double)lon;
+  double max_lat = min_lat + 1.0, max_lon = min_lon + 1.0;
+  if (latitude < min_lat || latitude > max_lat || longitude < min_lon || longitude > max_lon) return false;
+  double flat = (latitude - min_lat) * (double)(td.n_lat - 1);
+  double flon = (longitude - min_lon) * (double)(td.n_lon - 1);
+  int lat_int = sat_index(flat), lon_int = sat_index(flon);
+  double lat_frac = flat - (double)lat_int;
+  double lon_frac = flon - (double)lon_int;
+  if (lat_int == td.n_lat - 1) { // max-edge case, geotiff.rs:77-85
+    lat_int -= 1;
+    lat_frac += 1.0;
+  }
+  if (lon_int == td.n_lon - 1) {
+    lon_int -= 1;
+    lon_frac += 1.0;
+  }
+  const int16_t* row0 = tv.posts + td.offset + (int64_t)lat_int * td.n_lon + lon_int;
+  const int16_t* row1 = row0 + td.n_lon;
+  double e00 = (double)row0[0], e10 = (double)row0[1];
+  double e01 = (double)row1[0], e11 = (double)row1[1];
+  elev = e00 * (1.0 - lon_frac) * (1.0 - lat_frac) + e01 * (1.0 - lon_frac) * lat_frac +
+         e10 * lon_frac * (1.0 - lat_frac) + e11 * lon_frac * lat_frac;
+  return true;
+}
+ATMRT_HD double terrain_elev_or_zero(const TerrainView& tv, double lat, double lon) {
+  double e;
+  return terrain_get_elev(tv, lat, lon, e) ? e : 0.0; // .unwrap_or(0.0), utils.rs:28-31,84
+}
+
+// find_normal, utils.rs:15-40.  The two calculators (azimuth 0 and 90) are handled by one rolled
+// loop so the geodesic code is instantiated once, not four times (register pressure on the GPU).
+ATMRT_HD Vec3 find_normal(const Earth& e, const TerrainView& tv, double lat, double lon) {
+  const double DIFF = 15.0;
+  double diff_ns = 0.0, diff_ew = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int k = 0; k < 2; k++) {
+    DirCalc c;
+    dircalc_new(e, lat, lon, k == 0 ? 0.0 : 90.0, c);
+    double plat, plon, mlat, mlon;
+    coords_at_dist(e, c, DIFF, plat, plon);   // p_north / p_east
+    coords_at_dist(e, c, -DIFF, mlat, mlon);  // p_south / p_west
+    double d = terrain_elev_or_zero(tv, plat, plon) - terrain_elev_or_zero(tv, mlat, mlon);
+    if (k == 0) diff_ns = d;
+    else diff_ew = d;
+  }
+  Vec3 dn, de, du;
+  world_directions(e, lat, lon, dn, de, du);
+  Vec3 vec_ns = dn * (2.0 * DIFF) + du * diff_ns;
+  Vec3 vec_ew = de * (2.0 * DIFF) + du * diff_ew;
+  Vec3 normal = cross(vec_ew, vec_ns);
+  double len = dm_sqrt(normal.x * normal.x + normal.y * normal.y + normal.z * normal.z);
+  return normal / len;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray stepper (crate atm-refraction 0.6, source absent): RK4 on the Snell / Bouguer ODE
+// ---------------------------------------------------------------------------------------------
+
+struct RayState { // RayState {x, h, dh}
+  double x, h, dh;
+};
+
+struct Stepper {
+  double x, a, b;  // flat: a = h, b = dh/dx; spherical: a = r, b = dr/dphi
+  double h0, ang;  // straight rays: closed form from the start point
+};
+
+ATMRT_HD void stepper_init(Stepper& s, bool spherical, double radius, double h0, double ang_rad) {
+  s.x = 0.0;
+  s.h0 = h0;
+  s.ang = ang_rad;
+  if (spherical) {
+    s.a = h0 + radius;
+    s.b = s.a * dm_tan(ang_rad);
+  } else {
+    s.a = h0;
+    s.b = dm_tan(ang_rad);
+  }
+}
+
+ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b) {
+  if (spherical) {
+    double h = a - radius;
+    double n = refr_n(atm, h);
+    double dn = refr_dn(atm, h);
+    return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
+  }
+  double n = refr_n(atm, a);
+  double dn = refr_dn(atm, a);
+  return (1.0 + b * b) * dn / n;
+}
+
+// PathStepper::next: the state after one more step of `step` metres in x
+ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight,
+                               double step) {
+  RayState out;
+  if (straight) {
+    s.x = s.x + step;
+    if (spherical) {
+      double r0 = s.h0 + radius;
+      double phi = s.x / radius;
+      double c = dm_cos(s.ang + phi);
+      out.h = r0 * dm_cos(s.ang) / c - radius;
+      out.dh = dm_tan(s.ang + phi);
+    } else {
+      out.h = s.h0 + s.x * dm_tan(s.ang);
+      out.dh = dm_tan(s.ang);
+    }
+    out.x = s.x;
+    return out;
+  }
+  double d = spherical ? step / radius : step;
+  double half = 0.5 * d, sixth = d / 6.0;
+  double a = s.a, b = s.b;
+  double k1a = b;
+  double k1b = ray_accel(atm, spherical, radius, a, b);
+  double k2a = b + half * k1b;
+  double k2b = ray_accel(atm, spherical, radius, a + half * k1a, k2a);
+  double k3a = b + half * k2b;
+  double k3b = ray_accel(atm, spherical, radius, a + half * k2a, k3a);
+  double k4a = b + d * k3b;
+  double k4b = ray_accel(atm, spherical, radius, a + d * k3a, k4a);
+  s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
+  s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
+  s.x = s.x + step;
+  out.x = s.x;
+  if (spherical) {
+    out.h = s.a - radius;
+    out.dh = s.b / radius;
+  } else {
+    out.h = s.a;
+    out.dh = s.b;
+  }
+  return out;
+}
+
+// calc_dist, utils.rs:42-53
+ATMRT_HD double calc_dist(bool spherical, double radius, double x0, double h0, double x1, double h1) {
+  double dx = x1 - x0;
+  double dh = h1 - h0;
+  if (!spherical) return dm_sqrt(dx * dx + dh * dh);
+  double avg_h = (h1 + h0) / 2.0;
+  double dx2 = dx / radius * (avg_h + radius);
+  return dm_sqrt(dx2 * dx2 + dh * dh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pixel -> ray mapping
+// ---------------------------------------------------------------------------------------------
+
+// get_ray_elev / get_ray_dir, fast.rs:111-125 (i16 casts; `as` binds tighter than `/`)
+ATMRT_HD double fast_ray_elev(const atmrt_params_t& p, int y) {
+  double width = (double)p.width, height = (double)p.height;
+  double aspect = width / height;
+  double yy = (double)(int16_t)((int16_t)y - (int16_t)p.height / 2) / height;
+  return p.frame.tilt - yy * p.frame.fov / aspect;
+}
+ATMRT_HD double fast_ray_dir(const atmrt_params_t& p, int x) {
+  double width = (double)p.width;
+  double xx = (double)(int16_t)((int16_t)x - (int16_t)p.width / 2) / width;
+  return p.frame.direction + xx * p.frame.fov;
+}
+
+// Pinhole camera set-up shared by every pixel of a frame: rows of Rz(yaw) Ry(pitch) Rx(roll) as
+// nalgebra's Rotation3::from_euler_angles(0, -tilt, direction) builds them, and the focal length.
+struct Pinhole {
+  double m[9];
+  double z;
+};
+ATMRT_HD void pinhole_init(const atmrt_params_t& p, Pinhole& ph) {
+  double roll = 0.0, pitch = -dm_to_radians(p.frame.tilt), yaw = dm_to_radians(p.frame.direction);
+  double sr, cr, sp, cp, sy, cy;
+  dm_sincos(roll, &sr, &cr);
+  dm_sincos(pitch, &sp, &cp);
+  dm_sincos(yaw, &sy, &cy);
+  ph.m[0] = cy * cp; ph.m[1] = cy * sp * sr - sy * cr; ph.m[2] = cy * sp * cr + sy * sr;
+  ph.m[3] = sy * cp; ph.m[4] = sy * sp * sr + cy * cr; ph.m[5] = sy * sp * cr - cy * sr;
+  ph.m[6] = -sp;     ph.m[7] = cp * sr;                ph.m[8] = cp * cr;
+  ph.z = (double)p.width / 2.0 / dm_tan(dm_to_radians(p.frame.fov) / 2.0);
+}
+// RectilinearGenerator::get_ray_params, rectilinear.rs:78-100: direction and elevation in RADIANS
+ATMRT_HD void rect_ray_params(const atmrt_params_t& p, const Pinhole& ph, int px, int py, double& direction,
+                              double& elevation) {
+  double x = (double)(int16_t)((int16_t)px - (int16_t)p.width / 2);
+  double y = (double)(int16_t)((int16_t)py - (int16_t)p.height / 2);
+  double vx = ph.z, vy = x, vz = -y; // Vector3::new(z, x, -y)
+  double dx = ph.m[0] * vx + ph.m[1] * vy + ph.m[2] * vz;
+  double dy = ph.m[3] * vx + ph.m[4] * vy + ph.m[5] * vz;
+  double dz = ph.m[6] * vx + ph.m[7] * vy + ph.m[8] * vz;
+  double len = dm_sqrt(dx * dx + dy * dy + dz * dz);
+  dx /= len;
+  dy /= len;
+  dz /= len;
+  direction = dm_atan2(dy, dx);
+  elevation = dm_asin(dz);
+}
+
+// TracingState::interpolate for one scalar, utils.rs:108-125
+ATMRT_HD double lerp_ts(double a, double b, double prop) { return a + (b - a) * prop; }
+
+} // namespace atmrt

@@ -1,0 +1,108 @@
+// atmrt_kernels.h — launch interface between the C-ABI host code (atmrt_api.hip) and the gfx950
+// kernels (atmrt_kernels.hip).  Internal; the public surface is include/atmrt.h.
+#pragma once
+
+#include "atmrt_core.h"
+
+namespace atmrt {
+
+// Scene object resolved on the device (SerializableObject, object/mod.rs:185-190).
+struct ObjectDev {
+  int32_t kind;
+  int32_t tex_w, tex_h;
+  int32_t _pad;
+  double lat, lon, elev; // elev: Altitude::abs applied by k_resolve (object/mod.rs:166-175)
+  double r1, r2, height, width;
+  double color[4];
+  int64_t tex_offset;    // first byte of the RGBA8 texture in the texture pool
+};
+
+// Everything a kernel needs about the frame; passed by value (about 1.3 KB of kernel arguments).
+struct Frame {
+  atmrt_params_t p;
+  Earth earth;
+  AtmTable atm;
+  Pinhole ph;
+  TerrainView tv;
+  const double* alt;        // device scalar: observer altitude after Altitude::abs (params.rs:23-30)
+  const double* xs;         // xs[k] = 0 + step + ... + step (k additions): utils.rs:191-196 and the stepper's x
+  const ObjectDev* objects;
+  const uint8_t* textures;
+  int32_t n_objects;
+  int32_t n_t;              // terrain samples per column: #{k : xs[k] < max_distance}
+  int32_t n_path_cap;       // path elements per row when the ray never drops below -1000 m
+  int32_t c0, wl, h;        // pixel-column shard [c0, c0 + wl), image height
+  int32_t opaque;           // terrain_alpha == 1.0 and no objects: at most one trace point per pixel
+  int32_t _pad;
+};
+
+// Dense per-pixel outputs ([h][wl] row-major).  `normal` is planar [3][h][wl].
+struct DensePlanes {
+  double* azimuth;
+  double* elevation_angle;
+  uint32_t* hit_count;
+  double* lat;
+  double* lon;
+  double* distance;
+  double* elevation;
+  double* path_length;
+  double* normal;
+};
+
+// Packed trace points (generators/mod.rs:21-30), filled in pixel order.
+struct PackedHits {
+  double* lat;
+  double* lon;
+  double* distance;
+  double* elevation;
+  double* path_length;
+  double* normal; // [n][3]
+  uint32_t* color_tag;
+  double* rgba;   // [n][4]
+};
+
+// Scratch owned by the context, sized for the current frame.
+struct Workspace {
+  double* alt;            // [1]
+  DirCalc* colcalc;       // [wl]   Fast: per-column DirectionalCalc
+  double* prof;           // [n_t][wl] Fast: terrain profile, sample-major so a wavefront reads 64 columns coalesced
+  double* pelev;          // [h][n_path_cap] Fast: ray elevation per row
+  double* plen;           // [h][n_path_cap] Fast: running path length per row
+  int32_t* npath;         // [h]
+  int32_t* hit_step;      // [h][wl] first hit: index of the older sample of the pair, or -1
+  uint64_t* hit_offset;   // [h][wl] exclusive scan of hit_count
+  uint64_t* scan_tmp;     // block sums for the scan
+  uint64_t* counters;     // [0] ray-steps, [1] total hits
+  uint32_t* list_step;    // multi-hit: per trace point, the step index and ...
+  uint32_t* list_pixel;   // ... its pixel
+  double* rect_rec;       // Rectilinear: [4][n] ray elevation / path length at the two bracketing samples
+};
+
+// All launches go to `stream`; none of them synchronises or allocates.
+void launch_resolve(const Frame& f, Workspace& ws, ObjectDev* objects_mut, hipStream_t stream);
+void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,
+                        hipEvent_t ev_join, hipEvent_t* timing /* [0..1] phase A, [2..3] phase B */);
+void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
+void launch_fast_finalize(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
+void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched);
+void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count, hipStream_t stream);
+void launch_pack_first_hits(const Frame& f, Workspace& ws, const DensePlanes& dense, const PackedHits& packed,
+                            hipStream_t stream);
+// multi-hit (terrain_alpha < 1): count -> scan -> fill
+void launch_multi_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                       hipStream_t stream);
+
+void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense,
+                            const PackedHits& packed, hipStream_t stream);
+
+// harness kernels (diagnostic subcommands of the reference)
+void launch_get_elev(const Frame& f, size_t n, const double* lat, const double* lon, double* elev, uint8_t* valid,
+                     hipStream_t stream);
+void launch_ray_paths(const Frame& f, double h0, size_t n_angles, const double* angles_deg, int straight, double step,
+                      size_t n_steps, double* x, double* h, hipStream_t stream);
+void launch_atm_sample(const Frame& f, size_t n, const double* alt, double* t, double* p, double* nidx, double* dn,
+                       hipStream_t stream);
+void launch_coords_at_dist(const Frame& f, double lat0, double lon0, double dir, size_t n, const double* dist,
+                           double* lat, double* lon, hipStream_t stream);
+
+} // namespace atmrt

@@ -1,0 +1,800 @@
+// atmrt_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the ray-marching path.
+//
+// Wavefront = 64 lanes everywhere.  All arithmetic is IEEE binary64 with contraction disabled, in
+// the operation order of atmrt_core.h, so results are bit-identical to the CPU checker.
+//
+// Fast generator (fast.rs:22-98) as four kernels:
+//   k_fast_columns    per-column DirectionalCalc                  (utils.rs:183-189)
+//   k_terrain_profile phase A: terrain elevation per (sample, column)   (utils.rs:176-199, 84)
+//   k_fast_paths      phase B: one RK4 ray per image row          (utils.rs:136-174)
+//   k_fast_intersect  phase C: sign-change scan of get_single_pixel     (utils.rs:211-240)
+//   k_fast_finalize   TracePoint at the bracketing samples only   (utils.rs:108-125, 15-40)
+// Rectilinear generator (rectilinear.rs:102-186): k_rect_march, one ray per lane.
+#include "atmrt_kernels.h"
+
+namespace atmrt {
+
+static __device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// TracePoint (generators/mod.rs:21-30) of a terrain hit
+struct TracePointDev {
+  double lat, lon, distance, elevation, path_length;
+  Vec3 normal;
+};
+
+// One bracketing pair -> interpolated terrain TracePoint (utils.rs:222-236 with :108-125)
+static __device__ TracePointDev terrain_trace_point(const Frame& f, const Earth& e, double lat0, double lon0, double te0, double re0,
+                                                    double dist0, double pl0, double lat1, double lon1, double te1,
+                                                    double re1, double dist1, double pl1) {
+  double diff1 = re0 - te0;
+  double diff2 = re1 - te1;
+  double prop = diff1 / (diff1 - diff2);
+  Vec3 n0 = v3(0.0, 0.0, 0.0), n1 = n0;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) { // one instantiation of find_normal for both bracketing samples
+    Vec3 n = find_normal(e, f.tv, k == 0 ? lat0 : lat1, k == 0 ? lon0 : lon1);
+    if (k == 0) n0 = n;
+    else n1 = n;
+  }
+  TracePointDev tp;
+  tp.lat = lerp_ts(lat0, lat1, prop);
+  tp.lon = lerp_ts(lon0, lon1, prop);
+  tp.elevation = lerp_ts(te0, te1, prop);
+  tp.normal = v3(lerp_ts(n0.x, n1.x, prop), lerp_ts(n0.y, n1.y, prop), lerp_ts(n0.z, n1.z, prop));
+  tp.distance = lerp_ts(dist0, dist1, prop);
+  tp.path_length = lerp_ts(pl0, pl1, prop);
+  return tp;
+}
+
+static __device__ __forceinline__ void store_dense(const DensePlanes& o, size_t p, size_t plane, const TracePointDev& tp) {
+  o.lat[p] = tp.lat;
+  o.lon[p] = tp.lon;
+  o.distance[p] = tp.distance;
+  o.elevation[p] = tp.elevation;
+  o.path_length[p] = tp.path_length;
+  o.normal[p] = tp.normal.x;
+  o.normal[plane + p] = tp.normal.y;
+  o.normal[2 * plane + p] = tp.normal.z;
+}
+static __device__ __forceinline__ void store_dense_miss(const DensePlanes& o, size_t p, size_t plane) {
+  double n = qnan();
+  o.lat[p] = n;
+  o.lon[p] = n;
+  o.distance[p] = n;
+  o.elevation[p] = n;
+  o.path_length[p] = n;
+  o.normal[p] = n;
+  o.normal[plane + p] = n;
+  o.normal[2 * plane + p] = n;
+}
+static __device__ __forceinline__ void store_packed(const PackedHits& o, uint64_t k, const TracePointDev& tp, double alpha) {
+  o.lat[k] = tp.lat;
+  o.lon[k] = tp.lon;
+  o.distance[k] = tp.distance;
+  o.elevation[k] = tp.elevation;
+  o.path_length[k] = tp.path_length;
+  o.normal[3 * k] = tp.normal.x;
+  o.normal[3 * k + 1] = tp.normal.y;
+  o.normal[3 * k + 2] = tp.normal.z;
+  o.color_tag[k] = ATMRT_COLOR_TERRAIN;
+  o.rgba[4 * k] = 0.0;
+  o.rgba[4 * k + 1] = 0.0;
+  o.rgba[4 * k + 2] = 0.0;
+  o.rgba[4 * k + 3] = alpha;
+}
+
+// wave-wide sum of a 64-bit count, result valid in lane 0
+static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// The DirectionalCalc kind is a compile-time constant in the heavy kernels, so only one of the four
+// calculators (AzEq / FlDs / Spherical / Ellipsoid-Vincenty) is instantiated per kernel variant.
+template <int CALC>
+static __device__ __forceinline__ Earth earth_for(const Frame& f) {
+  Earth e = f.earth;
+  e.calc = CALC;
+  return e;
+}
+#define ATMRT_DISPATCH_CALC(calc, STMT)                  \
+  switch (calc) {                                        \
+    case 0: { constexpr int CALC = 0; STMT; } break;     \
+    case 1: { constexpr int CALC = 1; STMT; } break;     \
+    case 2: { constexpr int CALC = 2; STMT; } break;     \
+    default: { constexpr int CALC = 3; STMT; } break;    \
+  }
+
+// ---------------------------------------------------------------------------------------------
+// set-up: Altitude::abs for the observer and every object (params.rs:23-30, object/mod.rs:166-175)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_resolve(Frame f, double* alt, ObjectDev* objects, const atmrt_position_t* obj_pos) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    const atmrt_position_t& pos = f.p.position;
+    *alt = pos.altitude_kind == ATMRT_ALT_ABSOLUTE
+               ? pos.altitude
+               : terrain_elev_or_zero(f.tv, pos.latitude, pos.longitude) + pos.altitude;
+  }
+  if (i < f.n_objects) {
+    const atmrt_position_t pos = obj_pos[i];
+    objects[i].elev = pos.altitude_kind == ATMRT_ALT_ABSOLUTE
+                          ? pos.altitude
+                          : terrain_elev_or_zero(f.tv, pos.latitude, pos.longitude) + pos.altitude;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast generator
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fast_columns(Frame f, DirCalc* colcalc) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= f.wl) return;
+  double dir = fast_ray_dir(f.p, f.c0 + x);
+  DirCalc c;
+  dircalc_new(f.earth, f.p.position.latitude, f.p.position.longitude, dir, c);
+  colcalc[x] = c;
+}
+
+// Phase A.  A wavefront covers 64 adjacent columns at one sample index, so its profile store is one
+// coalesced 512-byte row segment and its terrain gathers fall on neighbouring posts of the mosaic.
+constexpr int PROFILE_SAMPLES_PER_BLOCK = 16;
+template <int CALC>
+__global__ __launch_bounds__(256) void k_terrain_profile(Frame f, const DirCalc* __restrict__ colcalc,
+                                                         double* __restrict__ prof) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int sub = threadIdx.x >> 6;
+  if (x >= f.wl) return;
+  const Earth e = earth_for<CALC>(f);
+  const DirCalc c = colcalc[x];
+  int i0 = blockIdx.y * PROFILE_SAMPLES_PER_BLOCK;
+  for (int k = sub; k < PROFILE_SAMPLES_PER_BLOCK; k += 4) {
+    int i = i0 + k;
+    if (i >= f.n_t) break;
+    double lat, lon;
+    coords_at_dist(e, c, f.xs[i], lat, lon);
+    prof[(size_t)i * f.wl + x] = terrain_elev_or_zero(f.tv, lat, lon);
+  }
+}
+
+// Phase B.  One lane integrates one row's ray; rows are independent and the chain is sequential.
+__global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__ pelev, double* __restrict__ plen,
+                                                   int32_t* __restrict__ npath) {
+  int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= f.h) return;
+  const bool sph = f.earth.spherical != 0;
+  const double radius = f.earth.shape_radius;
+  const bool straight = f.p.straight_rays != 0;
+  const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+  const double alt = *f.alt;
+  Stepper s;
+  stepper_init(s, sph, radius, alt, dm_to_radians(fast_ray_elev(f.p, y)));
+  size_t base = (size_t)y * f.n_path_cap;
+  pelev[base] = alt;
+  plen[base] = 0.0;
+  int n = 1;
+  double px = 0.0, ph = alt, path_length = 0.0;
+  // utils.rs:159-171: push, then stop once the PREVIOUS state is beyond max_distance or below -1000 m
+  while (n < f.n_path_cap) {
+    RayState st = stepper_next(s, f.atm, sph, radius, straight, step);
+    path_length += calc_dist(sph, radius, px, ph, st.x, st.h);
+    pelev[base + n] = st.h;
+    plen[base + n] = path_length;
+    n++;
+    if (px > max_dist || ph < -1000.0) break;
+    px = st.x;
+    ph = st.h;
+  }
+  npath[y] = n;
+}
+
+// Phase C.  Lanes = 64 adjacent columns, each wavefront owns RR adjacent rows.  The terrain value
+// prof[i][x] is loaded once per lane (coalesced) and reused for RR rows; the ray elevation
+// pelev[y][i] is wave-uniform (scalar loads).  MODE 0: opaque terrain, stop at the first hit.
+// MODE 1: count every sign change (terrain_alpha < 1).
+template <int RR, int MODE>
+__global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* __restrict__ prof,
+                                                        const double* __restrict__ pelev,
+                                                        const int32_t* __restrict__ npath,
+                                                        int32_t* __restrict__ hit_step,
+                                                        uint32_t* __restrict__ hit_count,
+                                                        unsigned long long* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = blockIdx.x * 64 + lane;
+  const bool xok = x < f.wl;
+  const int xc = xok ? x : f.wl - 1;
+  const int y0 = (blockIdx.y * 4 + wave) * RR;
+  const int cap = f.n_path_cap;
+  if (y0 >= f.h) return;
+
+  int nrow[RR];
+  double dprev[RR];
+  int first[RR];
+  unsigned cnt[RR];
+  int nmax = 0;
+  const double t0 = prof[xc];
+#pragma unroll
+  for (int r = 0; r < RR; r++) {
+    int y = y0 + r;
+    int n = 0;
+    if (y < f.h) {
+      n = npath[y];
+      n = n < f.n_t ? n : f.n_t; // Iterator::zip, fast.rs:59-62
+    }
+    nrow[r] = n;
+    nmax = n > nmax ? n : nmax;
+    first[r] = -1;
+    cnt[r] = 0;
+    dprev[r] = (y < f.h) ? pelev[(size_t)y * cap] - t0 : 0.0;
+  }
+  int open = 0; // rows of this lane still marching (MODE 0)
+#pragma unroll
+  for (int r = 0; r < RR; r++) open += nrow[r] > 1;
+
+  for (int i = 1; i < nmax; i++) {
+    const double t = prof[(size_t)i * f.wl + xc];
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      if (i < nrow[r]) {
+        const double d = pelev[(size_t)(y0 + r) * cap + i] - t;
+        const bool hit = dprev[r] * d < 0.0; // utils.rs:222
+        if (MODE == 0) {
+          if (hit && first[r] < 0) {
+            first[r] = i - 1;
+            open--;
+          } else if (i == nrow[r] - 1 && first[r] < 0) {
+            open--;
+          }
+        } else {
+          if (hit) {
+            if (first[r] < 0) first[r] = i - 1;
+            cnt[r]++;
+          }
+        }
+        dprev[r] = d;
+      }
+    }
+    if (MODE == 0 && __all(open <= 0)) break;
+  }
+
+  unsigned long long steps = 0;
+#pragma unroll
+  for (int r = 0; r < RR; r++) {
+    int y = y0 + r;
+    if (y < f.h && xok) {
+      size_t p = (size_t)y * f.wl + x;
+      hit_step[p] = first[r];
+      if (MODE == 0) {
+        hit_count[p] = first[r] >= 0 ? 1u : 0u;
+        steps += first[r] >= 0 ? (unsigned)(first[r] + 1) : (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
+      } else {
+        hit_count[p] = cnt[r];
+        steps += (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
+      }
+    }
+  }
+  steps = wave_sum(steps);
+  if (lane == 0 && steps) atomicAdd(&counters[0], steps);
+}
+
+// The two samples that bracket step s of pixel (x, y), from the caches
+static __device__ __forceinline__ TracePointDev fast_hit(const Frame& f, const Earth& e, const DirCalc& c, const double* prof, const double* pelev,
+                                         const double* plen, int x, int y, int s) {
+  double lat0, lon0, lat1, lon1;
+  double d0 = f.xs[s], d1 = f.xs[s + 1];
+  coords_at_dist(e, c, d0, lat0, lon0);
+  coords_at_dist(e, c, d1, lat1, lon1);
+  double te0 = prof[(size_t)s * f.wl + x], te1 = prof[(size_t)(s + 1) * f.wl + x];
+  size_t base = (size_t)y * f.n_path_cap;
+  double re0 = pelev[base + s], re1 = pelev[base + s + 1];
+  // TracingState::new(&first_terrain, first_path.elev, 0.0, 0.0) (utils.rs:208): path[0] is (0, alt, 0) anyway
+  double pl0 = plen[base + s], pl1 = plen[base + s + 1];
+  return terrain_trace_point(f, e, lat0, lon0, te0, re0, d0, pl0, lat1, lon1, te1, re1, d1, pl1);
+}
+
+template <int CALC>
+__global__ __launch_bounds__(256) void k_fast_finalize(Frame f, const DirCalc* __restrict__ colcalc,
+                                                       const double* __restrict__ prof,
+                                                       const double* __restrict__ pelev,
+                                                       const double* __restrict__ plen,
+                                                       const int32_t* __restrict__ hit_step, DensePlanes out) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= f.wl) return;
+  size_t plane = (size_t)f.wl * f.h;
+  size_t p = (size_t)y * f.wl + x;
+  double azimuth = fast_ray_dir(f.p, f.c0 + x); // fast.rs:67-72: a single wrap into [0, 360)
+  if (azimuth < 0.0) azimuth += 360.0;
+  else if (azimuth >= 360.0) azimuth -= 360.0;
+  out.azimuth[p] = azimuth;
+  out.elevation_angle[p] = fast_ray_elev(f.p, y);
+  int s = hit_step[p];
+  if (s < 0) {
+    store_dense_miss(out, p, plane);
+    return;
+  }
+  const DirCalc c = colcalc[x];
+  store_dense(out, p, plane, fast_hit(f, earth_for<CALC>(f), c, prof, pelev, plen, x, y, s));
+}
+
+// terrain_alpha < 1: second scan that lists every sign change of every pixel (step index + pixel)
+__global__ __launch_bounds__(256) void k_fast_list(Frame f, const double* __restrict__ prof,
+                                                   const double* __restrict__ pelev,
+                                                   const int32_t* __restrict__ npath,
+                                                   const uint64_t* __restrict__ hit_offset,
+                                                   uint32_t* __restrict__ list_step,
+                                                   uint32_t* __restrict__ list_pixel) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= f.wl) return;
+  int n = npath[y];
+  n = n < f.n_t ? n : f.n_t;
+  size_t p = (size_t)y * f.wl + x;
+  uint64_t k = hit_offset[p];
+  const double* row = pelev + (size_t)y * f.n_path_cap;
+  double dprev = row[0] - prof[x];
+  for (int i = 1; i < n; i++) {
+    double d = row[i] - prof[(size_t)i * f.wl + x];
+    if (dprev * d < 0.0) {
+      list_step[k] = (uint32_t)(i - 1);
+      list_pixel[k] = (uint32_t)p;
+      k++;
+    }
+    dprev = d;
+  }
+}
+
+template <int CALC>
+__global__ __launch_bounds__(256) void k_fast_finalize_list(Frame f, uint64_t n_hits,
+                                                            const DirCalc* __restrict__ colcalc,
+                                                            const double* __restrict__ prof,
+                                                            const double* __restrict__ pelev,
+                                                            const double* __restrict__ plen,
+                                                            const uint32_t* __restrict__ list_step,
+                                                            const uint32_t* __restrict__ list_pixel, PackedHits packed) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_hits) return;
+  uint32_t p = list_pixel[k];
+  int x = (int)(p % (uint32_t)f.wl), y = (int)(p / (uint32_t)f.wl);
+  const DirCalc c = colcalc[x];
+  store_packed(packed, k, fast_hit(f, earth_for<CALC>(f), c, prof, pelev, plen, x, y, (int)list_step[k]),
+               f.p.terrain_alpha);
+}
+
+// azimuth / elevation planes and the dense first-hit view of a packed multi-hit result
+__global__ __launch_bounds__(256) void k_dense_from_packed(Frame f, const uint64_t* __restrict__ hit_offset,
+                                                           PackedHits packed, DensePlanes out, int fast_angles) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= f.wl) return;
+  size_t plane = (size_t)f.wl * f.h;
+  size_t p = (size_t)y * f.wl + x;
+  if (fast_angles) {
+    double azimuth = fast_ray_dir(f.p, f.c0 + x);
+    if (azimuth < 0.0) azimuth += 360.0;
+    else if (azimuth >= 360.0) azimuth -= 360.0;
+    out.azimuth[p] = azimuth;
+    out.elevation_angle[p] = fast_ray_elev(f.p, y);
+  }
+  if (out.hit_count[p] == 0) {
+    store_dense_miss(out, p, plane);
+    return;
+  }
+  uint64_t k = hit_offset[p];
+  TracePointDev tp;
+  tp.lat = packed.lat[k];
+  tp.lon = packed.lon[k];
+  tp.distance = packed.distance[k];
+  tp.elevation = packed.elevation[k];
+  tp.path_length = packed.path_length[k];
+  tp.normal = v3(packed.normal[3 * k], packed.normal[3 * k + 1], packed.normal[3 * k + 2]);
+  store_dense(out, p, plane, tp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rectilinear generator: one ray per lane — per-step geodesic point, bilinear terrain gather
+// (4 int16 posts = 8 B), sign test, RK4 step (rectilinear.rs:161-185 driving utils.rs:201-289).
+// MODE 0: opaque, write the dense first hit.  MODE 1: count.  MODE 2: write packed trace points.
+// ---------------------------------------------------------------------------------------------
+// The march only records WHERE the ray crossed the terrain (step index + ray elevation and path
+// length at the two bracketing samples); k_rect_finalize rebuilds the geodesic points, the four
+// finite-difference terrain lookups per sample and the interpolation.  Keeping the hit epilogue out
+// of the march keeps the RK4 loop at ~135 VGPRs without scratch.
+struct RectRec {
+  double* re0; // ray elevation at the older sample   (planar: [n] each)
+  double* pl0; // path length at the older sample
+  double* re1;
+  double* pl1;
+};
+
+template <int MODE, int CALC>
+__global__ __launch_bounds__(256) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+                                                    const uint64_t* __restrict__ hit_offset, RectRec rec,
+                                                    uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                    unsigned long long* __restrict__ counters) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < plane;
+  unsigned long long steps = 0;
+  if (live) {
+    const Earth e = earth_for<CALC>(f);
+    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+    const bool sph = e.spherical != 0;
+    const double radius = e.shape_radius;
+    const bool straight = f.p.straight_rays != 0;
+    const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+    const bool opaque = f.p.terrain_alpha == 1.0;
+    const double alt = *f.alt;
+    double direction, elevation;
+    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+    DirCalc c;
+    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+    Stepper s;
+    stepper_init(s, sph, radius, alt, elevation);
+    unsigned count = 0;
+    int first = -1;
+    uint64_t k = MODE == 2 ? hit_offset[p] : 0;
+    // first sample (PathIterator::next at the start state); the reference would panic on an empty stream
+    if (!(0.0 > max_dist || alt < -1000.0)) {
+      double lat, lon;
+      coords_at_dist(e, c, 0.0, lat, lon);
+      double diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
+      double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
+      double sx = 0.0, sh = alt, path_length = 0.0;
+      for (int i = 1;; i++) {
+        RayState st = stepper_next(s, f.atm, sph, radius, straight, step);
+        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h);
+        sx = st.x;
+        sh = st.h;
+        if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
+        coords_at_dist(e, c, sx, lat, lon);
+        double diff1 = sh - terrain_elev_or_zero(f.tv, lat, lon);
+        steps++;
+        if (diff0 * diff1 < 0.0) { // utils.rs:222
+          if (MODE == 0) {
+            first = i - 1;
+            rec.re0[p] = re0;
+            rec.pl0[p] = pl0;
+            rec.re1[p] = sh;
+            rec.pl1[p] = path_length;
+          } else if (MODE == 2) {
+            list_step[k] = (uint32_t)(i - 1);
+            list_pixel[k] = (uint32_t)p;
+            rec.re0[k] = re0;
+            rec.pl0[k] = pl0;
+            rec.re1[k] = sh;
+            rec.pl1[k] = path_length;
+            k++;
+          }
+          count++;
+          if (opaque) break; // utils.rs:237-239, 283-285
+        }
+        diff0 = diff1;
+        re0 = sh;
+        pl0 = path_length;
+      }
+    }
+    if (MODE != 2) {
+      out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
+      out.elevation_angle[p] = dm_to_degrees(elevation);
+      out.hit_count[p] = count;
+    }
+    if (MODE == 0) hit_step[p] = first;
+  }
+  if (MODE != 2) {
+    steps = wave_sum(steps);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+  }
+}
+
+// TracePoint of a recorded crossing of pixel (x, y) at step s
+template <int CALC>
+static __device__ __forceinline__ TracePointDev rect_hit(const Frame& f, int x, int y, int s, double re0, double pl0,
+                                                         double re1, double pl1) {
+  const Earth e = earth_for<CALC>(f);
+  double direction, elevation;
+  rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+  DirCalc c;
+  dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+  double d0 = f.xs[s], d1 = f.xs[s + 1]; // the stepper's x: 0 + step + ... (same additions as xs)
+  double lat0, lon0, lat1, lon1;
+  coords_at_dist(e, c, d0, lat0, lon0);
+  coords_at_dist(e, c, d1, lat1, lon1);
+  double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
+  double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
+  return terrain_trace_point(f, e, lat0, lon0, te0, re0, d0, pl0, lat1, lon1, te1, re1, d1, pl1);
+}
+
+template <int CALC>
+__global__ __launch_bounds__(256) void k_rect_finalize(Frame f, const int32_t* __restrict__ hit_step, RectRec rec,
+                                                       DensePlanes out) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  int s = hit_step[p];
+  if (s < 0) {
+    store_dense_miss(out, p, plane);
+    return;
+  }
+  const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+  store_dense(out, p, plane, rect_hit<CALC>(f, x, y, s, rec.re0[p], rec.pl0[p], rec.re1[p], rec.pl1[p]));
+}
+
+template <int CALC>
+__global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_hits,
+                                                            const uint32_t* __restrict__ list_step,
+                                                            const uint32_t* __restrict__ list_pixel, RectRec rec,
+                                                            PackedHits packed) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_hits) return;
+  uint32_t p = list_pixel[k];
+  int x = (int)(p % (uint32_t)f.wl), y = (int)(p / (uint32_t)f.wl);
+  store_packed(packed, k, rect_hit<CALC>(f, x, y, (int)list_step[k], rec.re0[k], rec.pl0[k], rec.re1[k], rec.pl1[k]),
+               f.p.terrain_alpha);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of hit_count (u32) into hit_offset (u64): block sums -> one-block scan -> apply
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8; // per thread
+__global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restrict__ in, size_t n,
+                                                         uint64_t* __restrict__ block_sums) {
+  __shared__ unsigned long long sh[4];
+  size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_ITEMS;
+  unsigned long long v = 0;
+  for (int k = 0; k < SCAN_ITEMS; k++)
+    if (base + k < n) v += in[base + k];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void k_scan_sums(uint64_t* __restrict__ block_sums, size_t n_blocks,
+                                                   unsigned long long* __restrict__ counters) {
+  __shared__ unsigned long long sh[256];
+  size_t per = (n_blocks + 255) / 256;
+  size_t b0 = (size_t)threadIdx.x * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+  unsigned long long v = 0;
+  for (size_t b = b0; b < b1; b++) v += block_sums[b];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) { // Hillis–Steele inclusive scan
+    unsigned long long t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned long long run = sh[threadIdx.x] - v;
+  for (size_t b = b0; b < b1; b++) {
+    unsigned long long t = block_sums[b];
+    block_sums[b] = run;
+    run += t;
+  }
+  if (threadIdx.x == 255) counters[1] = sh[255];
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, size_t n,
+                                                    const uint64_t* __restrict__ block_sums,
+                                                    uint64_t* __restrict__ out) {
+  __shared__ unsigned long long sh[256];
+  size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_ITEMS;
+  unsigned vals[SCAN_ITEMS];
+  unsigned long long v = 0;
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    vals[k] = base + k < n ? in[base + k] : 0u;
+    v += vals[k];
+  }
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    unsigned long long t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned long long run = block_sums[blockIdx.x] + sh[threadIdx.x] - v;
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (base + k < n) out[base + k] = run;
+    run += vals[k];
+  }
+}
+
+// opaque mode: dense first hits -> packed list (pixel order)
+__global__ __launch_bounds__(256) void k_pack_first_hits(Frame f, const uint64_t* __restrict__ hit_offset,
+                                                         DensePlanes d, PackedHits packed) {
+  size_t plane = (size_t)f.wl * f.h;
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane || d.hit_count[p] == 0) return;
+  TracePointDev tp;
+  tp.lat = d.lat[p];
+  tp.lon = d.lon[p];
+  tp.distance = d.distance[p];
+  tp.elevation = d.elevation[p];
+  tp.path_length = d.path_length[p];
+  tp.normal = v3(d.normal[p], d.normal[plane + p], d.normal[2 * plane + p]);
+  store_packed(packed, hit_offset[p], tp, f.p.terrain_alpha);
+}
+
+// ---------------------------------------------------------------------------------------------
+// harness kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_get_elev(Frame f, size_t n, const double* lat, const double* lon, double* elev, uint8_t* valid) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double e = 0.0;
+  bool ok = terrain_get_elev(f.tv, lat[i], lon[i], e);
+  elev[i] = ok ? e : 0.0;
+  valid[i] = ok ? 1 : 0;
+}
+__global__ void k_ray_paths(Frame f, double h0, size_t n_angles, const double* angles_deg, int straight, double step,
+                            size_t n_steps, double* x, double* h) {
+  size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_angles) return;
+  const bool sph = f.earth.spherical != 0;
+  Stepper s;
+  stepper_init(s, sph, f.earth.shape_radius, h0, dm_to_radians(angles_deg[a]));
+  size_t base = a * (n_steps + 1);
+  x[base] = 0.0;
+  h[base] = h0;
+  for (size_t k = 1; k <= n_steps; k++) {
+    RayState st = stepper_next(s, f.atm, sph, f.earth.shape_radius, straight != 0, step);
+    x[base + k] = st.x;
+    h[base + k] = st.h;
+  }
+}
+__global__ void k_atm_sample(Frame f, size_t n, const double* alt, double* t, double* p, double* nidx, double* dn) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  t[i] = atm_temperature(f.atm, alt[i]);
+  p[i] = atm_pressure(f.atm, alt[i]);
+  nidx[i] = refr_n(f.atm, alt[i]);
+  dn[i] = refr_dn(f.atm, alt[i]);
+}
+__global__ void k_coords_at_dist(Frame f, double lat0, double lon0, double dir, size_t n, const double* dist, double* lat,
+                                 double* lon) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  DirCalc c;
+  dircalc_new(f.earth, lat0, lon0, dir, c);
+  coords_at_dist(f.earth, c, dist[i], lat[i], lon[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_resolve(const Frame& f, Workspace& ws, ObjectDev* objects_mut, hipStream_t stream) {
+  (void)objects_mut;
+  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, stream, f, ws.alt, (ObjectDev*)nullptr,
+                     (const atmrt_position_t*)nullptr);
+}
+
+constexpr int FAST_RR = 8;
+
+void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,
+                        hipEvent_t ev_join, hipEvent_t* timing) {
+  // phase B (few long sequential rays) runs beside phase A (many short samples) on a second stream
+  (void)hipEventRecord(ev, stream);
+  (void)hipStreamWaitEvent(stream2, ev, 0);
+  (void)hipEventRecord(timing[2], stream2);
+  hipLaunchKernelGGL(k_fast_paths, dim3(cdiv(f.h, 64)), dim3(64), 0, stream2, f, ws.pelev, ws.plen, ws.npath);
+  (void)hipEventRecord(timing[3], stream2);
+  (void)hipEventRecord(ev_join, stream2);
+  (void)hipEventRecord(timing[0], stream);
+  hipLaunchKernelGGL(k_fast_columns, dim3(cdiv(f.wl, 256)), dim3(256), 0, stream, f, ws.colcalc);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC>),
+                                                        dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)),
+                                                        dim3(256), 0, stream, f, ws.colcalc, ws.prof));
+  (void)hipEventRecord(timing[1], stream);
+  (void)hipStreamWaitEvent(stream, ev_join, 0);
+}
+
+void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  dim3 grid(cdiv(f.wl, 64), cdiv(f.h, 4 * FAST_RR));
+  if (f.opaque)
+    hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 0>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
+                       ws.hit_step, out.hit_count, (unsigned long long*)ws.counters);
+  else
+    hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 1>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
+                       ws.hit_step, out.hit_count, (unsigned long long*)ws.counters);
+}
+
+void launch_fast_finalize(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize<CALC>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0,
+                                                        stream, f, ws.colcalc, ws.prof, ws.pelev, ws.plen, ws.hit_step, out));
+}
+
+static RectRec carve_rec(double* base, size_t n) {
+  RectRec r;
+  r.re0 = base;
+  r.pl0 = base + n;
+  r.re1 = base + 2 * n;
+  r.pl1 = base + 3 * n;
+  return r;
+}
+
+void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
+  size_t n = (size_t)f.wl * f.h;
+  RectRec rec = carve_rec(ws.rect_rec, n);
+  if (f.opaque) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<0, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
+                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                          (unsigned long long*)ws.counters));
+    (void)hipEventRecord(ev_marched, stream);
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, ws.hit_step, rec, out));
+  } else {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<1, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
+                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                          (unsigned long long*)ws.counters));
+    (void)hipEventRecord(ev_marched, stream);
+  }
+}
+
+void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count, hipStream_t stream) {
+  size_t n = (size_t)f.wl * f.h;
+  unsigned nb = cdiv(n, 256 * SCAN_ITEMS);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, hit_count, n, ws.scan_tmp);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, ws.scan_tmp, (size_t)nb,
+                     (unsigned long long*)ws.counters);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, hit_count, n, ws.scan_tmp, ws.hit_offset);
+}
+
+void launch_pack_first_hits(const Frame& f, Workspace& ws, const DensePlanes& dense, const PackedHits& packed,
+                            hipStream_t stream) {
+  size_t n = (size_t)f.wl * f.h;
+  hipLaunchKernelGGL(k_pack_first_hits, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.hit_offset, dense, packed);
+}
+
+// terrain_alpha < 1, Rectilinear: second march lists every crossing, then one thread per trace point
+void launch_multi_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                       hipStream_t stream) {
+  size_t n = (size_t)f.wl * f.h;
+  RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<2, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f,
+                                                        dense, ws.hit_step, ws.hit_offset, rec, ws.list_step,
+                                                        ws.list_pixel, (unsigned long long*)ws.counters));
+  if (n_hits) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                          stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));
+  }
+  hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
+                     dense, 0);
+}
+
+void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense,
+                            const PackedHits& packed, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fast_list, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
+                     ws.hit_offset, ws.list_step, ws.list_pixel);
+  if (n_hits)
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                          stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,
+                                                          ws.list_step, ws.list_pixel, packed));
+  hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
+                     dense, 1);
+}
+
+void launch_get_elev(const Frame& f, size_t n, const double* lat, const double* lon, double* elev, uint8_t* valid,
+                     hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(k_get_elev, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, n, lat, lon, elev, valid);
+}
+void launch_ray_paths(const Frame& f, double h0, size_t n_angles, const double* angles_deg, int straight, double step,
+                      size_t n_steps, double* x, double* h, hipStream_t stream) {
+  if (n_angles)
+    hipLaunchKernelGGL(k_ray_paths, dim3(cdiv(n_angles, 64)), dim3(64), 0, stream, f, h0, n_angles, angles_deg,
+                       straight, step, n_steps, x, h);
+}
+void launch_atm_sample(const Frame& f, size_t n, const double* alt, double* t, double* p, double* nidx, double* dn,
+                       hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(k_atm_sample, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, n, alt, t, p, nidx, dn);
+}
+void launch_coords_at_dist(const Frame& f, double lat0, double lon0, double dir, size_t n, const double* dist,
+                           double* lat, double* lon, hipStream_t stream) {
+  if (n)
+    hipLaunchKernelGGL(k_coords_at_dist, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, lat0, lon0, dir, n, dist, lat, lon);
+}
+
+} // namespace atmrt

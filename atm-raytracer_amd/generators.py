@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's generator interface above the C ABI.
+
+Reference                                   here
+------------------------------------------  -----------------------------------------------
+Terrain::from_folder / get_elev             Terrain.from_folder / Terrain.get_elev
+  (src/terrain/mod.rs:66-83,120-126)
+Config::into_params(&terrain) -> Params     Params(config)
+trait Generator { fn generate(&self) }      Generator.generate() -> ResultPixels
+  FastGenerator::new(&params,&terrain,..)     FastGenerator(params, terrain)
+  RectilinearGenerator::new(..)               RectilinearGenerator(params, terrain)
+  InterpolatingRectilinearGenerator::new(..)  InterpolatingRectilinearGenerator(params, terrain)
+generator::generate's match on GeneratorDef  make_generator(params, terrain)
+  (src/generator/mod.rs:72-78)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi, _lib
+from ._lib import AtmrtError
+from .config import Config
+
+
+class Context:
+    """Owns one atmrt_ctx (one HIP device)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = C.c_void_p()
+        rc = self.lib.atmrt_ctx_create(C.byref(h), device)
+        if rc != 0:
+            raise AtmrtError(rc, self.lib.atmrt_last_error(None).decode())
+        self.handle = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise AtmrtError(rc, self.lib.atmrt_last_error(self.handle).decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.atmrt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Terrain:
+    """Terrain (src/terrain/mod.rs:55-57): tiles keyed by integer (lat, lon), resident in HBM."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or Context()
+        self.n_files = 0
+
+    @classmethod
+    def from_folder(cls, path, ctx=None):
+        t = cls(ctx)
+        n = C.c_int32()
+        t.ctx.check(t.ctx.lib.atmrt_terrain_load_dir(t.ctx.handle, os.fsencode(path), C.byref(n)))
+        t.n_files = n.value
+        return t
+
+    @classmethod
+    def from_tiles(cls, tiles, ctx=None):
+        """tiles: {(lat0, lon0): int16 array [n_lat][n_lon], south->north, west->east}."""
+        t = cls(ctx)
+        for (lat0, lon0), posts in tiles.items():
+            t.add_tile(lat0, lon0, posts)
+        return t
+
+    def add_tile(self, lat0, lon0, posts):
+        posts = np.ascontiguousarray(posts, dtype=np.int16)
+        self.ctx.check(self.ctx.lib.atmrt_terrain_add_tile(self.ctx.handle, lat0, lon0, posts.shape[0], posts.shape[1],
+                                                          posts.ctypes.data))
+        self.n_files += 1
+
+    def get_elev(self, lat, lon):
+        """Batched Terrain::get_elev; returns (elev, valid) arrays; valid=False where the reference returns None."""
+        lat = np.ascontiguousarray(np.atleast_1d(lat), dtype=np.float64)
+        lon = np.ascontiguousarray(np.atleast_1d(lon), dtype=np.float64)
+        elev = np.zeros_like(lat)
+        valid = np.zeros(lat.shape, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.atmrt_terrain_get_elev(self.ctx.handle, lat.size, lat.ctypes.data, lon.ctypes.data,
+                                                          elev.ctypes.data, valid.ctypes.data))
+        return elev, valid.astype(bool)
+
+
+class Params:
+    """`Params` (params.rs:496-505): Config resolved against a Terrain."""
+
+    def __init__(self, config: Config):
+        self.config = config
+        self.pod = config.params
+        self.atmosphere = config.atmosphere
+        self.objects = config.objects
+
+
+class ResultPixels(dict):
+    """Vec<Vec<ResultPixel>> as structure-of-arrays (see _abi.result_to_numpy).  `pixel(y, x)` rebuilds one
+    ResultPixel {elevation_angle, azimuth, trace_points[]} (generators/mod.rs:13-30)."""
+
+    def pixel(self, y, x):
+        off, cnt = int(self["hit_offset"][y, x]), int(self["hit_count"][y, x])
+        tps = []
+        for k in range(off, off + cnt):
+            tps.append({"lat": self["lat"][k], "lon": self["lon"][k], "distance": self["distance"][k],
+                        "elevation": self["elevation"][k], "path_length": self["path_length"][k],
+                        "normal": self["normal"][k], "color_tag": int(self["color_tag"][k]), "rgba": self["rgba"][k]})
+        return {"elevation_angle": self["elevation_angle"][y, x], "azimuth": self["azimuth"][y, x], "trace_points": tps}
+
+
+class Generator:
+    """trait Generator (generators/mod.rs:82-84)."""
+
+    KIND = None
+
+    def __init__(self, params: Params, terrain: Terrain):
+        self.params = params
+        self.terrain = terrain
+        self.ctx = terrain.ctx
+
+    def _configure(self):
+        pod = _abi.Params.from_buffer_copy(self.params.pod)
+        if self.KIND is not None:
+            pod.generator = self.KIND
+        self.ctx.check(self.ctx.lib.atmrt_set_params(self.ctx.handle, C.byref(pod)))
+        self.ctx.check(self.ctx.lib.atmrt_set_atmosphere(self.ctx.handle, C.byref(self.params.atmosphere)))
+        objs = self.params.objects
+        arr = (_abi.Object * max(1, len(objs)))(*objs)
+        self.ctx.check(self.ctx.lib.atmrt_objects_set(self.ctx.handle, arr, len(objs)))
+        return pod
+
+    def generate(self) -> ResultPixels:
+        self._configure()
+        res = _abi.Result()
+        self.ctx.check(self.ctx.lib.atmrt_generate(self.ctx.handle, C.byref(res)))
+        try:
+            return ResultPixels(_abi.result_to_numpy(res))
+        finally:
+            self.ctx.lib.atmrt_result_free(C.byref(res))
+
+    def generate_device(self, planes: "_abi.DevicePlanes"):
+        """Leave the first-hit planes in HBM (caller-owned device memory).  Returns (ray_steps, device_ms)."""
+        self._configure()
+        steps, ms = C.c_uint64(), C.c_double()
+        self.ctx.check(self.ctx.lib.atmrt_generate_device(self.ctx.handle, C.byref(planes), C.byref(steps), C.byref(ms)))
+        return steps.value, ms.value
+
+
+    def last_timings(self):
+        t = _abi.Timings()
+        self.ctx.check(self.ctx.lib.atmrt_last_timings(self.ctx.handle, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _abi.Timings._fields_}
+
+
+class FastGenerator(Generator):
+    KIND = _abi.GENERATORS["Fast"]
+
+
+class RectilinearGenerator(Generator):
+    KIND = _abi.GENERATORS["Rectilinear"]
+
+
+class InterpolatingRectilinearGenerator(Generator):
+    KIND = _abi.GENERATORS["InterpolatingRectilinear"]
+
+
+def make_generator(params: Params, terrain: Terrain) -> Generator:
+    """The `match params.output.generator` of generator::generate (src/generator/mod.rs:72-78)."""
+    return {0: FastGenerator, 1: InterpolatingRectilinearGenerator, 2: RectilinearGenerator}[params.pod.generator](params, terrain)
+
+
+# ---- integrator / sampler harnesses (ray_path.rs, atm_printer.rs, elev_profile.rs) -------------
+def ray_paths(ctx, h0, angles_deg, step, n_steps, straight=False):
+    ang = np.ascontiguousarray(angles_deg, dtype=np.float64)
+    x = np.zeros((ang.size, n_steps + 1))
+    h = np.zeros((ang.size, n_steps + 1))
+    ctx.check(ctx.lib.atmrt_ray_paths(ctx.handle, h0, ang.size, ang.ctypes.data, int(straight), step, n_steps,
+                                      x.ctypes.data, h.ctypes.data))
+    return x, h
+
+
+def atmosphere_sample(ctx, altitudes):
+    alt = np.ascontiguousarray(altitudes, dtype=np.float64)
+    outs = [np.zeros_like(alt) for _ in range(4)]
+    ctx.check(ctx.lib.atmrt_atmosphere_sample(ctx.handle, alt.size, alt.ctypes.data, *[o.ctypes.data for o in outs]))
+    return dict(zip(("temperature", "pressure", "n", "dn_dh"), outs))
+
+
+def coords_at_dist(ctx, lat0, lon0, dir_deg, dists):
+    d = np.ascontiguousarray(dists, dtype=np.float64)
+    lat, lon = np.zeros_like(d), np.zeros_like(d)
+    ctx.check(ctx.lib.atmrt_coords_at_dist(ctx.handle, lat0, lon0, dir_deg, d.size, d.ctypes.data, lat.ctypes.data,
+                                           lon.ctypes.data))
+    return lat, lon

@@ -1,0 +1,117 @@
+"""Synthetic inputs of SURVEY.md §8(d): seeded terrain on the DTED lattice, DTED file writer and
+the scenes S1..S5 that tests and bench.py use (the reference ships no data)."""
+import os
+
+import numpy as np
+
+from . import _abi
+from .config import Config
+
+SEED = 1234
+
+
+def _vnoise(u, v, seed):
+    """Value noise: bilinear blend of a seeded lattice of uniforms."""
+    iu, iv = np.floor(u).astype(np.int64), np.floor(v).astype(np.int64)
+    fu, fv = u - iu, v - iv
+
+    def lattice(i, j):
+        h = (i * 73856093) ^ (j * 19349663) ^ (seed * 83492791)
+        h = (h ^ (h >> 13)) * 1274126177
+        return ((h ^ (h >> 16)) & 0xFFFF) / 65535.0 * 2.0 - 1.0
+
+    a, b = lattice(iu, iv), lattice(iu + 1, iv)
+    c, d = lattice(iu, iv + 1), lattice(iu + 1, iv + 1)
+    su, sv = fu * fu * (3 - 2 * fu), fv * fv * (3 - 2 * fv)
+    return (a * (1 - su) + b * su) * (1 - sv) + (c * (1 - su) + d * su) * sv
+
+
+def synth_tile(lat0, lon0, level=1, seed=SEED, mosaic=(44, 6, 5, 5)):
+    """int16 posts [n][n] (south->north, west->east) of one 1-degree cell.  (u, v) is the fractional
+    position over the whole mosaic (lat_min, lon_min, n_lat_cells, n_lon_cells) so shared edges agree."""
+    n = {1: 1201, 2: 3601}[level] if level in (1, 2) else int(level)
+    lat = lat0 + np.arange(n) / (n - 1)
+    lon = lon0 + np.arange(n) / (n - 1)
+    v = ((lat - mosaic[0]) / mosaic[2])[:, None]
+    u = ((lon - mosaic[1]) / mosaic[3])[None, :]
+    e = (800.0 + 600.0 * np.sin(2 * np.pi * 3 * u) * np.cos(2 * np.pi * 2 * v) + 300.0 * np.sin(2 * np.pi * 11 * (u + v))
+         + 120.0 * _vnoise(64 * u + 0 * v, 64 * v + 0 * u, seed))
+    return np.clip(np.rint(e), 0, 4000).astype(np.int16)
+
+
+def synth_tiles(lat_range, lon_range, level=1, seed=SEED):
+    return {(la, lo): synth_tile(la, lo, level, seed) for la in lat_range for lo in lon_range}
+
+
+def write_dted(path, lat0, lon0, posts):
+    """Minimal DTED writer (MIL-PRF-89020B: UHL/DSI/ACC, 0xAA records, big-endian signed magnitude)."""
+    posts = np.asarray(posts, dtype=np.int16)
+    n_lat, n_lon = posts.shape
+    hdr = bytearray(b" " * 3428)
+
+    def ang(deg, is_lat):
+        hemi = ("S" if deg < 0 else "N") if is_lat else ("W" if deg < 0 else "E")
+        return f"{abs(deg):03d}0000{hemi}".encode()
+
+    hdr[0:4] = b"UHL1"
+    hdr[4:12] = ang(lon0, False)
+    hdr[12:20] = ang(lat0, True)
+    hdr[20:24] = f"{36000 // (n_lon - 1):04d}".encode()
+    hdr[24:28] = f"{36000 // (n_lat - 1):04d}".encode()
+    hdr[28:32] = b"NA  "
+    hdr[32:35] = b"U  "
+    hdr[47:51] = f"{n_lon:04d}".encode()
+    hdr[51:55] = f"{n_lat:04d}".encode()
+    hdr[55:56] = b"0"
+    hdr[80:84] = b"DSIU"
+    hdr[728:731] = b"ACC"
+    mag = np.abs(posts.astype(np.int32)).astype(np.uint16) | np.where(posts < 0, 0x8000, 0).astype(np.uint16)
+    with open(path, "wb") as f:
+        f.write(bytes(hdr))
+        for j in range(n_lon):
+            body = bytes([0xAA, (j >> 16) & 0xFF, (j >> 8) & 0xFF, j & 0xFF, (j >> 8) & 0xFF, j & 0xFF, 0, 0])
+            body += mag[:, j].astype(">u2").tobytes()
+            f.write(body + int(sum(body)).to_bytes(4, "big"))
+
+
+def write_terrain_dir(path, tiles):
+    os.makedirs(path, exist_ok=True)
+    for (la, lo), posts in tiles.items():
+        name = f"{'n' if la >= 0 else 's'}{abs(la):02d}_{'e' if lo >= 0 else 'w'}{abs(lo):03d}.dt{1 if posts.shape[0] == 1201 else 2}"
+        write_dted(os.path.join(path, name), la, lo, posts)
+
+
+def scene(name, width=None, height=None, generator="Fast", step=None, level=1, **over):
+    """Scenes S1..S5 / headline of SURVEY.md §8(d).  Returns (Config, tiles dict)."""
+    base = {
+        "S1": dict(tiles=None, pos=(0.5, 0.5, ("Absolute", 100.0)), dir=90.0, fov=60.0, tilt=-5.0, w=256, h=128, step=100.0,
+                   maxd=50_000.0, straight=True),
+        "S2": dict(tiles=([46], [8]), pos=(46.5, 8.5, ("Relative", 50.0)), dir=0.0, fov=60.0, tilt=0.0, w=1024, h=512,
+                   step=100.0, maxd=200_000.0, straight=False),
+        "S3": dict(tiles=([45, 46, 47], [7, 8, 9]), pos=(46.5, 8.5, ("Relative", 500.0)), dir=0.0, fov=120.0, tilt=-3.0,
+                   w=4096, h=2048, step=50.0, maxd=200_000.0, straight=False),
+        "S4": dict(tiles=([44, 45, 46, 47, 48], [6, 7, 8, 9, 10]), pos=(46.5, 8.5, ("Relative", 500.0)), dir=0.0, fov=120.0,
+                   tilt=-3.0, w=8192, h=4096, step=100.0, maxd=200_000.0, straight=False),
+    }
+    base["headline"] = dict(base["S3"], step=100.0)
+    b = base[name]
+    d = {
+        "view": {"position": {"latitude": b["pos"][0], "longitude": b["pos"][1], "altitude": {b["pos"][2][0]: b["pos"][2][1]}},
+                 "frame": {"direction": b["dir"], "fov": b["fov"], "tilt": b["tilt"], "max_distance": b["maxd"]}},
+        "earth_shape": {"Spherical": {"radius": 6371000.0}},
+        "straight_rays": b["straight"],
+        "simulation_step": step if step is not None else b["step"],
+        "output": {"width": width or b["w"], "height": height or b["h"], "generator": generator},
+    }
+    for k, v in over.items():
+        if k in ("earth_shape", "straight_rays", "simulation_step", "wavelength", "atmosphere"):
+            d[k] = v
+        elif k == "terrain_alpha":
+            d.setdefault("scene", {})["terrain_alpha"] = v
+        elif k in ("direction", "fov", "tilt", "max_distance"):
+            d["view"]["frame"][k] = v
+        else:
+            raise KeyError(k)
+    cfg = Config.from_dict(d)
+    tiles = synth_tiles(*b["tiles"], level=level) if b["tiles"] else {}
+    return cfg, tiles

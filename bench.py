@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the ray-marching path on MI355X, BASELINE.json's metric and config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--generator Rectilinear|Fast]
+
+A "step" is one full frame of the headline workload (4096x2048 panorama, 3x3 synthetic DTED level-2
+tiles, simulation_step 100 m, max_distance 200 km, spherical Earth + US-76 refraction) through the C ABI
+(atmrt_generate_device): terrain tiles and parameters are resident in HBM before the timed region, the
+per-pixel result planes stay in HBM.  With N > 1 (one process per GPU under torch.distributed.run) every rank
+marches its own pixel-column tile and the planes are all-gathered over RCCL/xGMI inside the step.
+
+Prints ONE JSON line (rank 0).  `value` = ray-steps marched by all ranks per second, where a ray-step is one
+sample-pair evaluation of get_single_pixel's loop under the reference's termination rule (utils.rs:211-287).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TF = 78.6   # vendor-published FP64 vector peak, secondary figure
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(generator, seconds_budget=30.0):
+    """The oracle (CPU restatement of the reference, glibc-libm flavour, OpenMP over all host cores) on a
+    bounded sample of the same scene: the headline frame at 1/16 (Fast) or 1/1024 (Rectilinear) of the pixels
+    with identical step / max_distance / field of view."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import Oracle
+    from atm_raytracer_amd import synth
+    w, h = (1024, 512) if generator == "Fast" else (128, 64)
+    cfg, tiles = synth.scene("headline", w, h, generator=generator, level=1)
+    oracle = Oracle("libm")
+    t = oracle.terrain_new(tiles)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    res = oracle.generate(cfg.params, cfg.atmosphere, t, [], cores)
+    dt = time.perf_counter() - t0
+    oracle.terrain_free(t)
+    return {"value": res["ray_steps"] / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+            "sample": f"headline scene at {w}x{h} px ({generator}), DTED level-1 tiles, {res['ray_steps']} ray-steps in {dt:.2f} s; "
+                      f"oracle/liboracle_libm.so (reference algorithm incl. eager normals), OpenMP",
+            "mpixels_per_s": w * h / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--generator", default="Rectilinear", choices=["Rectilinear", "Fast"])
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--dted-level", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also-fast", action="store_true", help="also time the Fast generator and report it under 'fast'")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from atm_raytracer_amd import _abi, generators, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-marching library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H = args.width, args.height
+    # pixel-column tiles: rank g owns [g*W/G, (g+1)*W/G)
+    c0, c1 = rank * W // world, (rank + 1) * W // world
+    wl = c1 - c0
+
+    t_setup = time.perf_counter()
+    cfg, tiles = synth.scene("headline", W, H, generator=args.generator, level=args.dted_level)
+    cfg.params.col_begin, cfg.params.col_end = (c0, c1) if world > 1 else (0, 0)
+    ctx = generators.Context(local_rank)
+    terrain = generators.Terrain.from_tiles(tiles, ctx)
+    log(f"[rank {rank}] scene ready in {time.perf_counter() - t_setup:.1f} s: {W}x{H}, columns [{c0},{c1}), "
+        f"{len(tiles)} tiles of {next(iter(tiles.values())).shape}")
+
+    def planes_for(width):
+        f64 = dict(dtype=torch.float64, device=dev)
+        t = {k: torch.empty((H, width), **f64) for k in ("azimuth", "elevation_angle", "lat", "lon", "distance", "elevation", "path_length")}
+        t["normal"] = torch.empty((3, H, width), **f64)
+        t["hit_count"] = torch.empty((H, width), dtype=torch.int32, device=dev)
+        return t
+
+    local = planes_for(wl)
+    pod = _abi.DevicePlanes(**{k: v.data_ptr() for k, v in local.items()})
+    gathered = None
+    if world > 1:
+        gathered = {k: torch.empty((world,) + tuple(v.shape), dtype=v.dtype, device=dev) for k, v in local.items()}
+
+    def make_step(generator_name):
+        cfg.params.generator = _abi.GENERATORS[generator_name]
+        gen = generators.make_generator(generators.Params(cfg), terrain)
+
+        def step():
+            steps, _ms = gen.generate_device(pod)  # returns after the library's stream has drained
+            if world > 1:
+                for k, v in local.items():  # one RCCL all-gather per result plane
+                    dist.all_gather_into_tensor(gathered[k], v)
+            return steps, gen.last_timings()
+        return step
+
+    def timed(generator_name, k_steps, warmup):
+        step = make_step(generator_name)
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        marched, phase = 0, []
+        for _ in range(k_steps):
+            s, tm = step()
+            marched += s
+            phase.append(tm)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        stats = torch.tensor([elapsed, float(marched)], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = stats[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tot = stats[1:].clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            elapsed, marched = float(tmax.item()), float(tot.item())
+        return elapsed, marched, phase
+
+    def roofline(generator_name, phase):
+        """Dominant kernel of the generator: algorithmic bytes (8 B per ray-step + 88 B per pixel
+        + 64 B per hit) over its mean launch duration from the library's HIP events."""
+        key = "march_ms" if generator_name == "Rectilinear" else max(("intersect_ms", "paths_ms", "profile_ms"), key=lambda k: np.mean([p[k] for p in phase]))
+        ms = float(np.mean([p[key] for p in phase]))
+        steps_per_launch = float(np.mean([p["ray_steps"] for p in phase]))
+        hits = int((local["hit_count"] > 0).sum().item())
+        algo_bytes = 8.0 * steps_per_launch + 88.0 * wl * H + 64.0 * hits
+        achieved = algo_bytes / (ms * 1e-3) / 1e9
+        kernel = {"march_ms": "k_rect_march", "intersect_ms": "k_fast_intersect", "paths_ms": "k_fast_paths", "profile_ms": "k_terrain_profile"}[key]
+        out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": None, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+               "phase_ms": {k: float(np.mean([p[k] for p in phase])) for k in phase[0] if k.endswith("_ms")}}
+        if generator_name == "Rectilinear":
+            # secondary, honest figure: the march is FP64-VALU bound, ~0.9 kFLOP per ray-step
+            tf = 900.0 * steps_per_launch / (ms * 1e-3) / 1e12
+            out["fp64_valu"] = {"achieved_tflops_est": tf, "peak_tflops": FP64_VALU_PEAK_TF, "frac_est": tf / FP64_VALU_PEAK_TF,
+                                "flop_per_ray_step_est": 900}
+        return out
+
+    elapsed, marched, phase = timed(args.generator, args.steps, args.warmup)
+    result = {
+        "metric": "ray-steps/sec/GPU (and Mpixels/sec) at 4096x2048, step=100 m, max_dist=200 km",
+        "value": marched / elapsed, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"headline {W}x{H} panorama, 3x3 synthetic DTED level-{args.dted_level} tiles, step 100 m, max_distance 200 km, "
+                               f"spherical Earth + US-76 refraction, fov 120, generator {args.generator}",
+                   "generator": args.generator, "width": W, "height": H, "parallelism": f"pixel-column tiles x{world}" if world > 1 else "single GPU"},
+        "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
+        "ray_steps_per_frame": marched / args.steps,
+        "value_per_gpu": marched / elapsed / world,
+        "roofline": roofline(args.generator, phase),
+    }
+    if args.also_fast and args.generator != "Fast":
+        e2, m2, ph2 = timed("Fast", args.steps, 1)
+        result["fast"] = {"value": m2 / e2, "unit": "ray-steps/s", "ms_per_step": e2 / args.steps * 1e3,
+                          "mpixels_per_s": W * H * args.steps / e2 / 1e6, "roofline": roofline("Fast", ph2),
+                          "note": "reference's default generator (params.rs:427-429): per-column terrain profile + per-row ray path"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args.generator)
+        except Exception as exc:  # the oracle is a checker, never a fallback: report, do not hide
+            result["cpu_baseline"] = {"value": None, "error": repr(exc)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

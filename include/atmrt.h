@@ -1,0 +1,243 @@
+/* atmrt.h — C ABI of the MI355X-native per-pixel ray-marching path of atm-raytracer.
+ *
+ * The reference has no FFI: its plug-in surface for this path is the Rust trait
+ *     pub trait Generator { fn generate(&self) -> Vec<Vec<ResultPixel>>; }
+ * (src/generator/generators/mod.rs:82-84), implemented by FastGenerator (fast.rs:21-108),
+ * RectilinearGenerator (rectilinear.rs:23-76) and InterpolatingRectilinearGenerator
+ * (interpolating_rectilinear.rs:110-162), each built from (&Params, &Terrain).  The entry points
+ * below are what a Rust `impl Generator for HipGenerator` binds (INTEGRATION.md shows the stub):
+ * plain pointers, sizes and #[repr(C)]-compatible PODs; all angles in DEGREES and all lengths in
+ * METRES exactly as in the reference's `Params` (src/generator/params.rs:496-505).
+ *
+ * Error convention: every call returns 0 on success or a negative atmrt_status; the message is
+ * available from atmrt_last_error().  The library never aborts the process (the reference
+ * panics: terrain/mod.rs:45,71,117, params.rs:681-691; a shim may turn a non-zero status into
+ * panic!/Err(String) to keep that behaviour).  A context is single-owner and not re-entrant.
+ */
+#ifndef ATMRT_H
+#define ATMRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATMRT_ABI_VERSION 1
+
+typedef enum atmrt_status {
+  ATMRT_OK = 0,
+  ATMRT_ERR_INVALID_ARGUMENT = -1, /* bad pointer, size or enum value */
+  ATMRT_ERR_NO_DEVICE = -2,        /* no gfx950 device / HIP runtime unavailable: never falls back to CPU */
+  ATMRT_ERR_HIP = -3,              /* a HIP call or kernel failed (message carries hipGetErrorString) */
+  ATMRT_ERR_IO = -4,               /* terrain directory or file unreadable (terrain/mod.rs:70-71) */
+  ATMRT_ERR_FORMAT = -5,           /* a file in the terrain directory is not a DTED tile (terrain/mod.rs:113-118) */
+  ATMRT_ERR_STATE = -6,            /* call order violated (e.g. generate before set_params) */
+  ATMRT_ERR_UNSUPPORTED = -7       /* schema element outside the hot-path scope (e.g. Spline temperature) */
+} atmrt_status;
+
+/* EarthModel, src/utils/earth_model/mod.rs:19-28 (same order as the Rust enum). */
+typedef enum atmrt_earth_kind {
+  ATMRT_EARTH_SIMPLE_SPHERE = 0,
+  ATMRT_EARTH_SPHERICAL = 1,             /* uses .radius */
+  ATMRT_EARTH_ELLIPSOID = 2,             /* uses .a, .b */
+  ATMRT_EARTH_WGS84 = 3,
+  ATMRT_EARTH_AZIMUTHAL_EQUIDISTANT = 4,
+  ATMRT_EARTH_FLAT_DISTORTED = 5,
+  ATMRT_EARTH_OBSERVER_AE = 6,           /* uses .radius as proj_radius */
+  ATMRT_EARTH_SIMPLE_OBSERVER_AE = 7
+} atmrt_earth_kind;
+
+typedef struct atmrt_earth_model {
+  int32_t kind; /* atmrt_earth_kind */
+  int32_t _pad;
+  double radius;
+  double a;
+  double b;
+} atmrt_earth_model_t;
+
+/* Altitude, params.rs:17-30. */
+typedef enum atmrt_altitude_kind { ATMRT_ALT_ABSOLUTE = 0, ATMRT_ALT_RELATIVE = 1 } atmrt_altitude_kind;
+
+/* Position, params.rs:32-40. */
+typedef struct atmrt_position {
+  double latitude;
+  double longitude;
+  int32_t altitude_kind; /* atmrt_altitude_kind */
+  int32_t _pad;
+  double altitude;
+} atmrt_position_t;
+
+/* Frame, params.rs:145-155. */
+typedef struct atmrt_frame {
+  double direction;
+  double tilt;
+  double fov;
+  double max_distance;
+} atmrt_frame_t;
+
+/* GeneratorDef, params.rs:387-392 (same order). */
+typedef enum atmrt_generator_kind {
+  ATMRT_GEN_FAST = 0,
+  ATMRT_GEN_INTERPOLATING_RECTILINEAR = 1,
+  ATMRT_GEN_RECTILINEAR = 2
+} atmrt_generator_kind;
+
+/* The subset of `Params` (params.rs:496-505) that reaches the generators. */
+typedef struct atmrt_params {
+  atmrt_position_t position;   /* view.position */
+  atmrt_frame_t frame;         /* view.frame */
+  atmrt_earth_model_t earth;   /* model; env.shape is derived from it (earth_model/mod.rs:95-112) */
+  double wavelength;           /* env.wavelength [m] */
+  double simulation_step;      /* [m] */
+  double terrain_alpha;        /* scene.terrain_alpha */
+  int32_t straight_rays;       /* bool */
+  int32_t generator;           /* atmrt_generator_kind, output.generator */
+  uint16_t width;              /* output.width  (u16 as in params.rs:398-402) */
+  uint16_t height;             /* output.height */
+  uint16_t col_begin;          /* pixel-column shard [col_begin, col_end) computed by this context; */
+  uint16_t col_end;            /*   0,0 means the whole width.  Multi-GPU: one context per rank. */
+} atmrt_params_t;
+
+/* AtmosphereDef of crate atm-refraction 0.6 (schema: reference README.md:283-323).  Only `Linear`
+ * temperature functions are inside the hot-path scope this round; `Spline` returns
+ * ATMRT_ERR_UNSUPPORTED from the host-side parser. */
+#define ATMRT_MAX_ATM_LAYERS 16
+typedef struct atmrt_atmosphere {
+  double pressure_altitude;          /* pressure fixed point */
+  double pressure;                   /* [Pa] */
+  double temperature_altitude;       /* temperature_fixed_point */
+  double temperature;                /* [K] */
+  int32_t n_layers;                  /* >= 1: layer 0 = first_temperature_function (from -inf) */
+  int32_t _pad;
+  double layer_altitude[ATMRT_MAX_ATM_LAYERS]; /* layer k (k>=1) applies at altitude >= layer_altitude[k]; [0] unused */
+  double layer_gradient[ATMRT_MAX_ATM_LAYERS]; /* dT/dh [K/m] */
+} atmrt_atmosphere_t;
+
+/* Scene objects, src/object/mod.rs:19-75,119-131 after ConfShape::into_shape. */
+typedef enum atmrt_object_kind { ATMRT_OBJ_FRUSTUM = 0, ATMRT_OBJ_BILLBOARD = 1 } atmrt_object_kind;
+typedef struct atmrt_object {
+  int32_t kind; /* atmrt_object_kind; Cylinder = Frustum{r1=r2}, Cone = Frustum{r2=0} (object/mod.rs:44-54) */
+  int32_t _pad;
+  atmrt_position_t position;
+  double r1, r2;       /* frustum bottom / top radius */
+  double height;       /* frustum or billboard height */
+  double width;        /* billboard width */
+  double color[4];     /* frustum RGBA in [0,1]; alpha defaults to 1.0 in the YAML (object/mod.rs:140-146) */
+  const uint8_t* texture_rgba; /* billboard texture, row-major top row first, 4 bytes per texel; borrowed during the call */
+  uint32_t texture_width;
+  uint32_t texture_height;
+} atmrt_object_t;
+
+/* PixelColor tag of a trace point, generators/mod.rs:45-49. */
+typedef enum atmrt_color_tag { ATMRT_COLOR_TERRAIN = 0, ATMRT_COLOR_RGBA = 1 } atmrt_color_tag;
+
+/* Vec<Vec<ResultPixel>> (generators/mod.rs:13-30) flattened to structure-of-arrays.
+ * Pixel p = y * width + (x - col_begin), row-major like result[y][x] (fast.rs:52-92).
+ * Trace points of pixel p are hits [hit_offset[p], hit_offset[p] + hit_count[p]) in march order. */
+typedef struct atmrt_result {
+  uint32_t width;  /* columns in this shard */
+  uint32_t height;
+  uint64_t n_pixels;
+  uint64_t n_hits;
+  double* azimuth;         /* [n_pixels] degrees */
+  double* elevation_angle; /* [n_pixels] degrees */
+  uint32_t* hit_count;     /* [n_pixels] */
+  uint64_t* hit_offset;    /* [n_pixels] */
+  double* lat;             /* [n_hits] TracePoint.lat */
+  double* lon;
+  double* distance;
+  double* elevation;
+  double* path_length;
+  double* normal;          /* [n_hits][3] */
+  uint32_t* color_tag;     /* [n_hits] atmrt_color_tag */
+  double* rgba;            /* [n_hits][4]; Terrain(alpha) -> {0,0,0,alpha} */
+  uint64_t ray_steps;      /* sample pairs examined under the reference's termination rule (utils.rs:211-287) */
+  double device_ms;        /* device time of the generate call, HIP events */
+} atmrt_result_t;
+
+/* Device-resident first-hit planes of one shard, written by atmrt_generate_device (caller-owned
+ * device memory, e.g. torch tensors; the library only writes them).  Used by bench.py and by the
+ * multi-GPU path so that results stay in HBM for the RCCL all-gather. */
+typedef struct atmrt_device_planes {
+  double* azimuth;         /* [H][Wshard] */
+  double* elevation_angle;
+  uint32_t* hit_count;     /* total trace points of the pixel */
+  double* lat;             /* first trace point; NaN where hit_count == 0 */
+  double* lon;
+  double* distance;
+  double* elevation;
+  double* path_length;
+  double* normal;          /* [3][H][Wshard] planar */
+} atmrt_device_planes_t;
+
+typedef struct atmrt_ctx atmrt_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int atmrt_abi_version(void);
+/* device_ordinal: HIP device index (LOCAL_RANK under torchrun).  Fails with ATMRT_ERR_NO_DEVICE
+ * when no GPU is present — there is no CPU path in this library. */
+int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal);
+void atmrt_ctx_destroy(atmrt_ctx* ctx);
+/* Message of the last failing call on ctx (or of the last failing atmrt_ctx_create when ctx == NULL). */
+const char* atmrt_last_error(const atmrt_ctx* ctx);
+
+/* ---- terrain: replaces Terrain::{from_folder,get_elev} (terrain/mod.rs:55-126) + crate dted 0.2 */
+/* Scan a directory of DTED files (every entry must parse, as terrain/mod.rs:113-118 panics otherwise). */
+int atmrt_terrain_load_dir(atmrt_ctx* ctx, const char* path, int32_t* n_files);
+/* Register one 1-degree cell directly.  posts: n_lat rows (south to north) of n_lon posts (west to east). */
+int atmrt_terrain_add_tile(atmrt_ctx* ctx, int32_t lat0, int32_t lon0, int32_t n_lat, int32_t n_lon,
+                           const int16_t* posts);
+int atmrt_terrain_clear(atmrt_ctx* ctx);
+/* Batched Terrain::get_elev on the device: valid[i] = 0 where the reference returns None. */
+int atmrt_terrain_get_elev(atmrt_ctx* ctx, size_t n, const double* lat, const double* lon, double* elev,
+                           uint8_t* valid);
+
+/* ---- configuration ------------------------------------------------------------------------ */
+void atmrt_params_default(atmrt_params_t* p);         /* Config::default, params.rs:481-494 */
+void atmrt_atmosphere_us76(atmrt_atmosphere_t* a);    /* AtmosphereDef::us_76 */
+int atmrt_set_params(atmrt_ctx* ctx, const atmrt_params_t* p);
+int atmrt_set_atmosphere(atmrt_ctx* ctx, const atmrt_atmosphere_t* a);
+int atmrt_objects_set(atmrt_ctx* ctx, const atmrt_object_t* objects, size_t n); /* scene.objects, in order */
+
+/* ---- the path ----------------------------------------------------------------------------- */
+/* Generator::generate for the generator named in params (generators/mod.rs:82-84).  The result is
+ * library-allocated host memory; release with atmrt_result_free. */
+int atmrt_generate(atmrt_ctx* ctx, atmrt_result_t* out);
+void atmrt_result_free(atmrt_result_t* r);
+/* Same computation, results left in HBM in caller-provided planes; ray_steps/device_ms optional. */
+int atmrt_generate_device(atmrt_ctx* ctx, const atmrt_device_planes_t* planes, uint64_t* ray_steps,
+                          double* device_ms);
+
+/* Device time of each phase of the last atmrt_generate / atmrt_generate_device call, measured with HIP
+ * events recorded on the library's own streams (a caller's events on another stream cannot see them). */
+typedef struct atmrt_timings {
+  double total_ms;     /* first launch to last launch of the call */
+  double profile_ms;   /* Fast phase A: k_fast_columns + k_terrain_profile   (utils.rs:176-199) */
+  double paths_ms;     /* Fast phase B: k_fast_paths, concurrent with phase A (utils.rs:136-174) */
+  double intersect_ms; /* Fast phase C: k_fast_intersect                      (utils.rs:201-289) */
+  double march_ms;     /* Rectilinear: k_rect_march                           (rectilinear.rs:161-185) */
+  double finalize_ms;  /* trace-point epilogue: k_fast_finalize / k_rect_finalize */
+  double pack_ms;      /* scan + packing / multi-hit fill, when requested */
+  uint64_t ray_steps;
+  uint64_t n_hits;
+} atmrt_timings_t;
+int atmrt_last_timings(atmrt_ctx* ctx, atmrt_timings_t* out);
+
+/* ---- integrator / sampler harnesses (the reference's diagnostic subcommands) ---------------- */
+/* output-ray-paths (src/ray_path.rs:65-103): for each elevation angle [deg] step the ray n_steps
+ * times from height h0 with `step` metres; x and h are [n_angles][n_steps+1] including the start. */
+int atmrt_ray_paths(atmrt_ctx* ctx, double h0, size_t n_angles, const double* angles_deg, int32_t straight,
+                    double step, size_t n_steps, double* x, double* h);
+/* output-atm (src/atm_printer.rs:37-46): T [K], p [Pa], refractive index n and dn/dh at altitudes. */
+int atmrt_atmosphere_sample(atmrt_ctx* ctx, size_t n, const double* altitude, double* temperature,
+                            double* pressure, double* n_index, double* dn_dh);
+/* DirectionalCalc::coords_at_dist (directional_calc.rs:5-7) for the context's earth model. */
+int atmrt_coords_at_dist(atmrt_ctx* ctx, double lat0, double lon0, double dir_deg, size_t n, const double* dist,
+                         double* lat, double* lon);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATMRT_H */

@@ -1,0 +1,163 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle_{det,libm}.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+import sys
+sys.path.insert(0, ROOT)
+from atm_raytracer_amd import _abi  # noqa: E402  (POD structs shared with the C ABI)
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class EnvAtm(C.Structure):
+    _fields_ = [("n", C.c_int)] + [(k, C.c_double * _abi.MAX_ATM_LAYERS) for k in ("hb", "tb", "pb", "lapse", "from_", "expo")] + [("k_refr", C.c_double)]
+
+
+class DirCalc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("radius", C.c_double), ("pos", Vec3), ("dir", Vec3), ("start_lat", C.c_double),
+                ("start_lon", C.c_double), ("dir_deg", C.c_double)] + [(k, C.c_double) for k in ("b", "f", "red_lat", "lon", "az1", "alfa", "sig1", "cap_a", "cap_b", "cap_c")]
+
+
+class Oracle:
+    """One flavour ('det' or 'libm') of the oracle library."""
+
+    def __init__(self, flavour="det"):
+        path = os.path.join(ORACLE_DIR, f"liboracle_{flavour}.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        self.flavour = flavour
+        L.oracle_flavour.restype = C.c_char_p
+        assert L.oracle_flavour().decode() == flavour
+        L.oracle_terrain_new.restype = C.c_void_p
+        L.oracle_terrain_free.argtypes = [C.c_void_p]
+        L.oracle_terrain_add_tile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_terrain_load_dir.argtypes = [C.c_void_p, C.c_char_p]
+        L.oracle_terrain_get_elev.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.oracle_dted_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_generate.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.Atmosphere), C.c_void_p,
+                                      C.POINTER(_abi.Object), C.c_size_t, C.c_int, C.POINTER(_abi.Result)]
+        L.oracle_result_free.argtypes = [C.POINTER(_abi.Result)]
+        L.oracle_atm_compile.argtypes = [C.POINTER(_abi.Atmosphere), C.c_double, C.POINTER(EnvAtm)]
+        for f in ("oracle_atm_temperature", "oracle_atm_pressure", "oracle_n", "oracle_dn"):
+            getattr(L, f).argtypes = [C.POINTER(EnvAtm), C.c_double]
+            getattr(L, f).restype = C.c_double
+        L.oracle_atmosphere_us76.argtypes = [C.POINTER(_abi.Atmosphere)]
+        L.oracle_dircalc_new.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double, C.c_double, C.POINTER(DirCalc)]
+        L.oracle_coords_at_dist.argtypes = [C.POINTER(DirCalc), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.oracle_as_cartesian.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double, C.c_double]
+        L.oracle_as_cartesian.restype = Vec3
+        L.oracle_world_directions.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double] + [C.POINTER(Vec3)] * 3
+        L.oracle_ray_paths.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.Atmosphere), C.c_double, C.c_size_t, C.c_void_p,
+                                       C.c_int, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
+
+    # ---- terrain -------------------------------------------------------------------------
+    def terrain_new(self, tiles=None):
+        t = self.lib.oracle_terrain_new()
+        for (lat0, lon0), posts in (tiles or {}).items():
+            posts = np.ascontiguousarray(posts, dtype=np.int16)
+            rc = self.lib.oracle_terrain_add_tile(t, lat0, lon0, posts.shape[0], posts.shape[1], posts.ctypes.data)
+            assert rc == 0
+        return t
+
+    def terrain_free(self, t):
+        self.lib.oracle_terrain_free(t)
+
+    def terrain_load_dir(self, path):
+        t = self.lib.oracle_terrain_new()
+        n = self.lib.oracle_terrain_load_dir(t, path.encode())
+        return t, n
+
+    def get_elev(self, t, lat, lon):
+        e = C.c_double()
+        ok = self.lib.oracle_terrain_get_elev(t, lat, lon, C.byref(e))
+        return e.value if ok else None
+
+    def dted_write(self, path, lat0, lon0, posts):
+        posts = np.ascontiguousarray(posts, dtype=np.int16)
+        rc = self.lib.oracle_dted_write(path.encode(), lat0, lon0, posts.shape[0], posts.shape[1], posts.ctypes.data)
+        assert rc == 0
+
+    # ---- atmosphere ----------------------------------------------------------------------
+    def us76(self):
+        a = _abi.Atmosphere()
+        self.lib.oracle_atmosphere_us76(C.byref(a))
+        return a
+
+    def env(self, atm=None, wavelength=530e-9):
+        e = EnvAtm()
+        atm = atm or self.us76()
+        assert self.lib.oracle_atm_compile(C.byref(atm), wavelength, C.byref(e)) == 0
+        return e
+
+    def n(self, env, h):
+        return self.lib.oracle_n(C.byref(env), h)
+
+    def dn(self, env, h):
+        return self.lib.oracle_dn(C.byref(env), h)
+
+    def temperature(self, env, h):
+        return self.lib.oracle_atm_temperature(C.byref(env), h)
+
+    def pressure(self, env, h):
+        return self.lib.oracle_atm_pressure(C.byref(env), h)
+
+    # ---- geodesy -------------------------------------------------------------------------
+    def coords_at_dist(self, earth, lat0, lon0, dir_deg, dists):
+        c = DirCalc()
+        self.lib.oracle_dircalc_new(C.byref(earth), lat0, lon0, dir_deg, C.byref(c))
+        lat, lon = C.c_double(), C.c_double()
+        out = np.zeros((len(dists), 2))
+        for i, d in enumerate(dists):
+            self.lib.oracle_coords_at_dist(C.byref(c), float(d), C.byref(lat), C.byref(lon))
+            out[i] = (lat.value, lon.value)
+        return out
+
+    def as_cartesian(self, earth, lat, lon, elev):
+        v = self.lib.oracle_as_cartesian(C.byref(earth), lat, lon, elev)
+        return np.array([v.x, v.y, v.z])
+
+    def world_directions(self, earth, lat, lon):
+        n, e, u = Vec3(), Vec3(), Vec3()
+        self.lib.oracle_world_directions(C.byref(earth), lat, lon, C.byref(n), C.byref(e), C.byref(u))
+        return tuple(np.array([v.x, v.y, v.z]) for v in (n, e, u))
+
+    # ---- generators ----------------------------------------------------------------------
+    def generate(self, params, atm=None, terrain=None, objects=None, n_threads=0):
+        own = terrain is None
+        if own:
+            terrain = self.lib.oracle_terrain_new()
+        atm = atm or self.us76()
+        objs = objects or []
+        arr = (_abi.Object * max(1, len(objs)))(*objs)
+        res = _abi.Result()
+        rc = self.lib.oracle_generate(C.byref(params), C.byref(atm), terrain, arr, len(objs), n_threads, C.byref(res))
+        if own:
+            self.lib.oracle_terrain_free(terrain)
+        if rc != 0:
+            raise RuntimeError(f"oracle_generate failed: {rc}")
+        out = _abi.result_to_numpy(res)
+        self.lib.oracle_result_free(C.byref(res))
+        return out
+
+    def ray_paths(self, params, h0, angles_deg, step, n_steps, straight=False, atm=None):
+        atm = atm or self.us76()
+        ang = np.ascontiguousarray(angles_deg, dtype=np.float64)
+        x = np.zeros((len(ang), n_steps + 1))
+        h = np.zeros((len(ang), n_steps + 1))
+        rc = self.lib.oracle_ray_paths(C.byref(params), C.byref(atm), h0, len(ang), ang.ctypes.data, int(straight), step,
+                                       n_steps, x.ctypes.data, h.ctypes.data)
+        assert rc == 0
+        return x, h

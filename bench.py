@@ -32,16 +32,17 @@ def log(*a):
 
 def cpu_baseline(generator, seconds_budget=30.0):
     """The oracle (CPU restatement of the reference, glibc-libm flavour, OpenMP over all host cores) on a
-    bounded sample of the same scene: the headline frame at 1/16 (Fast) or 1/1024 (Rectilinear) of the pixels
-    with identical step / max_distance / field of view."""
+    bounded sample of the same scene: the headline frame at 1/4 (Fast) or 1/64 (Rectilinear) of the pixels
+    with identical step / max_distance / field of view (about 10-30 s of CPU work on 16 threads)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
     from atm_raytracer_amd import synth
-    w, h = (1024, 512) if generator == "Fast" else (128, 64)
+    w, h = (2048, 1024) if generator == "Fast" else (512, 256)
     cfg, tiles = synth.scene("headline", w, h, generator=generator, level=1)
     oracle = Oracle("libm")
     t = oracle.terrain_new(tiles)
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share of the host; never fan out over the whole machine
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("ATMRT_CPU_THREADS", "16")))
     t0 = time.perf_counter()
     res = oracle.generate(cfg.params, cfg.atmosphere, t, [], cores)
     dt = time.perf_counter() - t0
@@ -85,8 +86,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H = args.width, args.height
-    # pixel-column tiles: rank g owns [g*W/G, (g+1)*W/G)
-    c0, c1 = rank * W // world, (rank + 1) * W // world
+    from atm_raytracer_amd.sharding import column_shard
+    c0, c1 = column_shard(W, rank, world)  # pixel-column tiles: rank g owns [g*W/G, (g+1)*W/G)
     wl = c1 - c0
 
     t_setup = time.perf_counter()
@@ -108,7 +109,7 @@ def main():
     pod = _abi.DevicePlanes(**{k: v.data_ptr() for k, v in local.items()})
     gathered = None
     if world > 1:
-        gathered = {k: torch.empty((world,) + tuple(v.shape), dtype=v.dtype, device=dev) for k, v in local.items()}
+        gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in local.items()}
 
     def make_step(generator_name):
         cfg.params.generator = _abi.GENERATORS[generator_name]
@@ -158,8 +159,17 @@ def main():
         algo_bytes = 8.0 * steps_per_launch + 88.0 * wl * H + 64.0 * hits
         achieved = algo_bytes / (ms * 1e-3) / 1e9
         kernel = {"march_ms": "k_rect_march", "intersect_ms": "k_fast_intersect", "paths_ms": "k_fast_paths", "profile_ms": "k_terrain_profile"}[key]
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+        if os.path.exists(pmc_file) and world == 1 and (W, H) == (4096, 2048):
+            # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (counters cannot be read from inside the process); FETCH_SIZE doubled per the gfx950 note
+            pmc = json.load(open(pmc_file))
+            for name, v in pmc.items():
+                if kernel in name and "finalize" not in name:
+                    traffic, traffic_src = v["hbm_bytes_per_launch_fetch_x2"], "profiles/pmc_hbm_latest.json"
         out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-               "traffic": None, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
                "phase_ms": {k: float(np.mean([p[k] for p in phase])) for k in phase[0] if k.endswith("_ms")}}
         if generator_name == "Rectilinear":
             # secondary, honest figure: the march is FP64-VALU bound, ~0.9 kFLOP per ray-step

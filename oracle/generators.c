@@ -41,7 +41,7 @@ static double elev_or_zero(const oracle_terrain* t, double lat, double lon) {
 }
 
 /* find_normal, utils.rs:15-40 */
-static ovec3 find_normal(const atmrt_earth_model_t* model, double lat, double lon, const oracle_terrain* terrain) {
+ovec3 oracle_find_normal(const atmrt_earth_model_t* model, double lat, double lon, const oracle_terrain* terrain) {
   const double DIFF = 15.0;
   oracle_dircalc ns_calc, ew_calc;
   double nlat, nlon, slat, slon, elat, elon, wlat, wlon, diff_ew, diff_ns, len;
@@ -87,7 +87,7 @@ static double calc_dist(const gen_ctx* g, oracle_ray_state old_state, oracle_ray
 static terrain_data terrain_data_from_lat_lon(const gen_ctx* g, double lat, double lon) {
   terrain_data td;
   size_t i;
-  td.normal = find_normal(&g->params->earth, lat, lon, g->terrain);
+  td.normal = oracle_find_normal(&g->params->earth, lat, lon, g->terrain);
   td.n_close = 0;
   td.close = NULL;
   for (i = 0; i < g->n_objects; i++) {

@@ -92,6 +92,9 @@ int oracle_terrain_get_elev(const oracle_terrain* t, double lat, double lon, dou
 int oracle_dted_write(const char* path, int lat0, int lon0, int n_lat, int n_lon, const int16_t* posts);
 int oracle_dted_read(const char* path, int* lat0, int* lon0, int* n_lat, int* n_lon, int16_t** posts);
 
+/* find_normal, utils.rs:15-40 */
+ovec3 oracle_find_normal(const atmrt_earth_model_t* model, double lat, double lon, const oracle_terrain* terrain);
+
 /* ---- generators (src/generator/generators) ------------------------------------------------ */
 int oracle_generate(const atmrt_params_t* params, const atmrt_atmosphere_t* atm, const oracle_terrain* terrain,
                     const atmrt_object_t* objects, size_t n_objects, int n_threads, atmrt_result_t* out);

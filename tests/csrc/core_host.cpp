@@ -1,0 +1,72 @@
+// Test-only host build of the PRODUCT's numerics header (atm-raytracer_amd/csrc/atmrt_core.h) so that the
+// operation order of the HIP kernels' device functions can be compared bit-for-bit with the oracle on the CPU,
+// without a GPU.  Never linked into the product; the product has no CPU path.
+#include "../../atm-raytracer_amd/csrc/atmrt_core.h"
+#include <vector>
+using namespace atmrt;
+
+extern "C" {
+int ch_atm(const atmrt_atmosphere_t* def, double wavelength, size_t n, const double* h, double* t, double* p, double* nn, double* dn) {
+  AtmTable a;
+  if (atm_compile(*def, wavelength, a)) return -1;
+  for (size_t i = 0; i < n; i++) { t[i] = atm_temperature(a, h[i]); p[i] = atm_pressure(a, h[i]); nn[i] = refr_n(a, h[i]); dn[i] = refr_dn(a, h[i]); }
+  return 0;
+}
+int ch_coords(const atmrt_earth_model_t* m, double lat0, double lon0, double dir, size_t n, const double* d, double* lat, double* lon) {
+  Earth e;
+  if (earth_resolve(*m, e)) return -1;
+  DirCalc c;
+  dircalc_new(e, lat0, lon0, dir, c);
+  for (size_t i = 0; i < n; i++) coords_at_dist(e, c, d[i], lat[i], lon[i]);
+  return 0;
+}
+int ch_cart(const atmrt_earth_model_t* m, double lat, double lon, double elev, double* out12) {
+  Earth e;
+  if (earth_resolve(*m, e)) return -1;
+  Vec3 c = as_cartesian(e, lat, lon, elev), n, ea, up;
+  world_directions(e, lat, lon, n, ea, up);
+  double v[12] = {c.x, c.y, c.z, n.x, n.y, n.z, ea.x, ea.y, ea.z, up.x, up.y, up.z};
+  for (int i = 0; i < 12; i++) out12[i] = v[i];
+  return 0;
+}
+int ch_ray_path(const atmrt_atmosphere_t* def, const atmrt_earth_model_t* m, double wavelength, double h0, double ang_deg, int straight,
+                double step, size_t n_steps, double* x, double* h) {
+  AtmTable a;
+  Earth e;
+  if (atm_compile(*def, wavelength, a) || earth_resolve(*m, e)) return -1;
+  Stepper s;
+  stepper_init(s, e.spherical != 0, e.shape_radius, h0, dm_to_radians(ang_deg));
+  x[0] = 0.0; h[0] = h0;
+  for (size_t k = 1; k <= n_steps; k++) {
+    RayState st = stepper_next(s, a, e.spherical != 0, e.shape_radius, straight != 0, step);
+    x[k] = st.x; h[k] = st.h;
+  }
+  return 0;
+}
+// one tile only: elevation + normal at points
+int ch_terrain(const atmrt_earth_model_t* m, int lat0, int lon0, int n_lat, int n_lon, const int16_t* posts, size_t n, const double* lat,
+               const double* lon, double* elev, int* valid, double* normal3) {
+  Earth e;
+  if (earth_resolve(*m, e)) return -1;
+  TileDesc td{0, n_lat, n_lon};
+  int32_t cell = 0;
+  TerrainView tv{posts, &td, &cell, lat0, lon0, 1, 1};
+  for (size_t i = 0; i < n; i++) {
+    double ev = 0.0;
+    valid[i] = terrain_get_elev(tv, lat[i], lon[i], ev) ? 1 : 0;
+    elev[i] = ev;
+    Vec3 nr = find_normal(e, tv, lat[i], lon[i]);
+    normal3[3 * i] = nr.x; normal3[3 * i + 1] = nr.y; normal3[3 * i + 2] = nr.z;
+  }
+  return 0;
+}
+int ch_pixels(const atmrt_params_t* p, double* fast_dir, double* fast_elev, double* rect_dir, double* rect_elev) {
+  Pinhole ph;
+  pinhole_init(*p, ph);
+  for (int x = 0; x < p->width; x++) fast_dir[x] = fast_ray_dir(*p, x);
+  for (int y = 0; y < p->height; y++) fast_elev[y] = fast_ray_elev(*p, y);
+  for (int y = 0; y < p->height; y++)
+    for (int x = 0; x < p->width; x++) rect_ray_params(*p, ph, x, y, rect_dir[y * p->width + x], rect_elev[y * p->width + x]);
+  return 0;
+}
+}

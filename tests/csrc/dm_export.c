@@ -1,0 +1,7 @@
+/* Test-only: exports detmath.h functions over arrays so tests/test_detmath.py can bound them against libm. */
+#include "../../atm-raytracer_amd/csrc/detmath.h"
+#include <stddef.h>
+#define V1(name) void t_##name(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_##name(x[i]); }
+V1(sin) V1(cos) V1(tan) V1(asin) V1(atan) V1(exp) V1(log) V1(sqrt) V1(floor)
+void t_atan2(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
+void t_pow(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_pow(a[i], b[i]); }

@@ -60,6 +60,9 @@ class Oracle:
         L.oracle_as_cartesian.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double, C.c_double]
         L.oracle_as_cartesian.restype = Vec3
         L.oracle_world_directions.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double] + [C.POINTER(Vec3)] * 3
+        L.oracle_find_normal.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double, C.c_void_p]
+        L.oracle_find_normal.restype = Vec3
+        L.oracle_dted_read.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.POINTER(C.c_int16))]
         L.oracle_ray_paths.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.Atmosphere), C.c_double, C.c_size_t, C.c_void_p,
                                        C.c_int, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
 
@@ -89,6 +92,20 @@ class Oracle:
         posts = np.ascontiguousarray(posts, dtype=np.int16)
         rc = self.lib.oracle_dted_write(path.encode(), lat0, lon0, posts.shape[0], posts.shape[1], posts.ctypes.data)
         assert rc == 0
+
+    def find_normal(self, earth, t, lat, lon):
+        v = self.lib.oracle_find_normal(C.byref(earth), lat, lon, t)
+        return np.array([v.x, v.y, v.z])
+
+    def dted_read(self, path):
+        lat0, lon0, nlat, nlon = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        posts = C.POINTER(C.c_int16)()
+        rc = self.lib.oracle_dted_read(path.encode(), C.byref(lat0), C.byref(lon0), C.byref(nlat), C.byref(nlon), C.byref(posts))
+        if rc != 0:
+            return None
+        arr = np.ctypeslib.as_array(posts, shape=(nlat.value, nlon.value)).copy()
+        C.CDLL(None).free(posts)
+        return lat0.value, lon0.value, arr
 
     # ---- atmosphere ----------------------------------------------------------------------
     def us76(self):

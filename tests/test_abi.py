@@ -1,0 +1,57 @@
+"""The C-ABI library loads, exports every symbol include/atmrt.h declares, agrees on struct sizes with the
+ctypes mirror, and refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from atm_raytracer_amd import _abi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "atmrt.h")).read()
+    declared = set(re.findall(r"\b(atmrt_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_match_the_header(lib):
+    for which, st in enumerate((_abi.Params, _abi.Atmosphere, _abi.Object, _abi.Result, _abi.DevicePlanes, _abi.EarthModel,
+                                _abi.Position, _abi.Frame)):
+        assert lib.atmrt_abi_sizeof(which) == C.sizeof(st), st.__name__
+
+
+def test_defaults_match_the_reference(lib):
+    p = _abi.Params()
+    lib.atmrt_params_default(C.byref(p))
+    assert (p.width, p.height, p.frame.fov, p.frame.max_distance) == (640, 480, 30.0, 150_000.0)  # params.rs:419-425,156-162
+    assert (p.simulation_step, p.wavelength, p.terrain_alpha, p.generator) == (50.0, 530e-9, 1.0, 0)  # :473-479,76-78,427-429
+    assert (p.earth.kind, p.earth.radius) == (_abi.EARTH_KINDS["Spherical"], 6_371_000.0)  # :467-471
+    assert (p.position.altitude_kind, p.position.altitude) == (_abi.ALT_RELATIVE, 1.0)  # :42-44
+    a = _abi.Atmosphere()
+    lib.atmrt_atmosphere_us76(C.byref(a))
+    assert a.n_layers == 7 and a.pressure == 101325.0 and a.temperature == 288.15 and a.layer_gradient[0] == -0.0065
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.atmrt_ctx_create(C.byref(h), 0) == _abi.ERR_NO_DEVICE
+    assert b"no CPU path" in lib.atmrt_last_error(None)
+    from atm_raytracer_amd import generators
+    with pytest.raises(_lib.AtmrtError):
+        generators.Context(0)

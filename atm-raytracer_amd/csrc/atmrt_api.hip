@@ -77,11 +77,14 @@ struct atmrt_ctx {
   int n_t = 0, n_path_cap = 0;
   bool xs_dirty = true;
 
-  std::vector<atmrt_object_t> objects;
+  std::vector<ObjectDev> objects;      // host image of the device table (altitude kind in _pad until k_resolve)
+  std::vector<uint8_t> textures;       // RGBA8 pool
+  bool objects_dirty = true;
 
   // workspace
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
-      d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io;
+      d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
+      d_ccount, d_coffset, d_clist;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -251,7 +254,8 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   for (DevBuf* b : {&c->d_posts, &c->d_tiles, &c->d_cells, &c->d_xs, &c->d_alt, &c->d_colcalc, &c->d_prof, &c->d_pelev,
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
-                    &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_dense, &c->d_packed, &c->d_io})
+                    &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
+                    &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_dense, &c->d_packed, &c->d_io})
     b->release();
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -447,8 +451,41 @@ extern "C" int atmrt_set_params(atmrt_ctx* c, const atmrt_params_t* p) {
 
 extern "C" int atmrt_objects_set(atmrt_ctx* c, const atmrt_object_t* objects, size_t n) {
   if (!c || (n && !objects)) return ATMRT_ERR_INVALID_ARGUMENT;
-  if (n) return c->fail(ATMRT_ERR_UNSUPPORTED, "scene objects are not implemented on the device yet");
-  c->objects.clear();
+  if (n > 1000000) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "too many objects");
+  std::vector<ObjectDev> objs(n);
+  std::vector<uint8_t> pool;
+  for (size_t i = 0; i < n; i++) {
+    const atmrt_object_t& s = objects[i];
+    ObjectDev& o = objs[i];
+    memset(&o, 0, sizeof o);
+    if (s.kind != ATMRT_OBJ_FRUSTUM && s.kind != ATMRT_OBJ_BILLBOARD)
+      return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "object %zu: unknown kind %d", i, s.kind);
+    if (s.position.altitude_kind != ATMRT_ALT_ABSOLUTE && s.position.altitude_kind != ATMRT_ALT_RELATIVE)
+      return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "object %zu: unknown altitude kind", i);
+    o.kind = s.kind;
+    o._pad = s.position.altitude_kind;
+    o.lat = s.position.latitude;
+    o.lon = s.position.longitude;
+    o.elev = s.position.altitude;
+    o.r1 = s.r1;
+    o.r2 = s.r2;
+    o.height = s.height;
+    o.width = s.width;
+    for (int k = 0; k < 4; k++) o.color[k] = s.color[k];
+    if (s.kind == ATMRT_OBJ_BILLBOARD) {
+      // Image::get_pixel clamps to (0, w - 2): f64::clamp panics for textures smaller than 2x2 (object/mod.rs:95,100)
+      if (!s.texture_rgba || s.texture_width < 2 || s.texture_height < 2 || s.texture_width > 16384 || s.texture_height > 16384)
+        return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "object %zu: a billboard needs an RGBA8 texture of at least 2x2", i);
+      o.tex_w = (int32_t)s.texture_width;
+      o.tex_h = (int32_t)s.texture_height;
+      o.tex_offset = (int64_t)pool.size();
+      size_t bytes = (size_t)s.texture_width * s.texture_height * 4;
+      pool.insert(pool.end(), s.texture_rgba, s.texture_rgba + bytes);
+    }
+  }
+  c->objects.swap(objs);
+  c->textures.swap(pool);
+  c->objects_dirty = true;
   return ATMRT_OK;
 }
 
@@ -493,9 +530,19 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   HIP_TRY(c, c->d_alt.reserve(sizeof(double)));
   f.alt = c->d_alt.as<double>();
   f.xs = c->d_xs.as<double>();
-  f.objects = nullptr;
-  f.textures = nullptr;
-  f.n_objects = 0;
+  // the device table is rewritten by k_resolve every frame (Altitude::abs depends on the terrain), so upload it each time
+  if (!c->objects.empty()) {
+    HIP_TRY(c, c->d_objects.reserve(c->objects.size() * sizeof(ObjectDev)));
+    HIP_TRY(c, hipMemcpy(c->d_objects.ptr, c->objects.data(), c->objects.size() * sizeof(ObjectDev), hipMemcpyHostToDevice));
+    if (c->objects_dirty && !c->textures.empty()) {
+      HIP_TRY(c, c->d_textures.reserve(c->textures.size()));
+      HIP_TRY(c, hipMemcpy(c->d_textures.ptr, c->textures.data(), c->textures.size(), hipMemcpyHostToDevice));
+    }
+    c->objects_dirty = false;
+  }
+  f.objects = c->objects.empty() ? nullptr : c->d_objects.as<ObjectDev>();
+  f.textures = c->d_textures.as<uint8_t>();
+  f.n_objects = (int32_t)c->objects.size();
   f.n_t = c->n_t;
   f.n_path_cap = c->n_path_cap;
   f.c0 = (p.col_begin == 0 && p.col_end == 0) ? 0 : p.col_begin;
@@ -511,7 +558,19 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   HIP_TRY(c, c->d_counters.reserve(4 * sizeof(uint64_t)));
   HIP_TRY(c, c->d_hit_step.reserve(npx * sizeof(int32_t)));
   HIP_TRY(c, c->d_hit_offset.reserve(npx * sizeof(uint64_t)));
-  HIP_TRY(c, c->d_scan_tmp.reserve((npx / 2048 + 2) * sizeof(uint64_t)));
+  size_t nsamples = f.n_objects && f.p.generator != ATMRT_GEN_RECTILINEAR ? (size_t)f.n_t * f.wl : 0;
+  HIP_TRY(c, c->d_scan_tmp.reserve((std::max(npx, nsamples) / 2048 + 2) * sizeof(uint64_t)));
+  if (nsamples) {
+    HIP_TRY(c, c->d_plat.reserve(nsamples * sizeof(double)));
+    HIP_TRY(c, c->d_plon.reserve(nsamples * sizeof(double)));
+    HIP_TRY(c, c->d_ccount.reserve(nsamples * sizeof(uint32_t)));
+    HIP_TRY(c, c->d_coffset.reserve(nsamples * sizeof(uint64_t)));
+  }
+  ws->plat = c->d_plat.as<double>();
+  ws->plon = c->d_plon.as<double>();
+  ws->ccount = c->d_ccount.as<uint32_t>();
+  ws->coffset = c->d_coffset.as<uint64_t>();
+  ws->clist = c->d_clist.as<uint32_t>();
   if (f.p.generator != ATMRT_GEN_RECTILINEAR) {
     HIP_TRY(c, c->d_colcalc.reserve((size_t)f.wl * sizeof(DirCalc)));
     HIP_TRY(c, c->d_prof.reserve((size_t)f.n_t * f.wl * sizeof(double)));
@@ -586,11 +645,30 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   hipStream_t s = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev_t0, s));
   HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint64_t), s));
-  launch_resolve(f, ws, nullptr, s);
+  launch_resolve(f, ws, c->d_objects.as<ObjectDev>(), s);
   // phase events: [0..1] profile, [2..3] paths (stream2), [4..5] intersect / march, [5..6] finalize, [7..8] pack
   hipEvent_t* ev = c->ev;
   const bool fast = f.p.generator == ATMRT_GEN_FAST;
-  if (fast) {
+  const bool general = f.n_objects > 0; // scenes with objects: full get_single_pixel, count -> scan -> fill
+  if (fast && general) {
+    launch_fast_caches(f, ws, s, c->stream2, c->ev_fork, c->ev_join, ev);
+    launch_close_count(f, ws, s);
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(cnt, ws.counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, c->d_clist.reserve((cnt[3] + 1) * sizeof(uint32_t)));
+    ws.clist = c->d_clist.as<uint32_t>();
+    launch_close_fill(f, ws, s);
+    HIP_TRY(c, hipEventRecord(ev[4], s));
+    launch_trace_count(f, ws, dense, s);
+    HIP_TRY(c, hipEventRecord(ev[5], s));
+    HIP_TRY(c, hipEventRecord(ev[6], s));
+  } else if (general) {
+    HIP_TRY(c, hipEventRecord(ev[4], s));
+    launch_trace_count(f, ws, dense, s);
+    HIP_TRY(c, hipEventRecord(ev[5], s));
+    HIP_TRY(c, hipEventRecord(ev[6], s));
+  } else if (fast) {
     launch_fast_caches(f, ws, s, c->stream2, c->ev_fork, c->ev_join, ev);
     HIP_TRY(c, hipEventRecord(ev[4], s));
     launch_fast_intersect(f, ws, dense, s);
@@ -622,6 +700,10 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
       if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
         HIP_TRY(c, c->d_rect_rec.reserve(4 * (n_hits + 1) * sizeof(double)));
         ws.rect_rec = c->d_rect_rec.as<double>();
+      }
+      if (general) {
+        launch_trace_fill(f, ws, n_hits, dense, packed, s);
+      } else if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
         launch_multi_fill(f, ws, n_hits, dense, packed, s);
       } else {
         launch_multi_fill_fast(f, ws, n_hits, dense, packed, s);
@@ -659,6 +741,9 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     t.n_hits = counters[1];
     c->timings = t;
   }
+  if (counters[2])
+    return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step or "
+                   "more than %d objects close to one sample", (unsigned long long)counters[2], 12, 8);
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;

@@ -3,19 +3,9 @@
 #pragma once
 
 #include "atmrt_core.h"
+#include "atmrt_objects.h"
 
 namespace atmrt {
-
-// Scene object resolved on the device (SerializableObject, object/mod.rs:185-190).
-struct ObjectDev {
-  int32_t kind;
-  int32_t tex_w, tex_h;
-  int32_t _pad;
-  double lat, lon, elev; // elev: Altitude::abs applied by k_resolve (object/mod.rs:166-175)
-  double r1, r2, height, width;
-  double color[4];
-  int64_t tex_offset;    // first byte of the RGBA8 texture in the texture pool
-};
 
 // Everything a kernel needs about the frame; passed by value (about 1.3 KB of kernel arguments).
 struct Frame {
@@ -76,10 +66,24 @@ struct Workspace {
   uint32_t* list_step;    // multi-hit: per trace point, the step index and ...
   uint32_t* list_pixel;   // ... its pixel
   double* rect_rec;       // Rectilinear: [4][n] ray elevation / path length at the two bracketing samples
+  // scenes with objects (Fast): geodesic point of every sample and the objects close to it (utils.rs:74-80)
+  double* plat;           // [n_t][wl]
+  double* plon;           // [n_t][wl]
+  uint32_t* ccount;       // [n_t][wl] number of close objects
+  uint64_t* coffset;      // [n_t][wl] exclusive scan of ccount
+  uint32_t* clist;        // object indices, ascending per sample
 };
 
 // All launches go to `stream`; none of them synchronises or allocates.
 void launch_resolve(const Frame& f, Workspace& ws, ObjectDev* objects_mut, hipStream_t stream);
+// scenes with objects / translucent terrain + objects: general tracer (count -> scan -> fill)
+void launch_fast_profile_ll(const Frame& f, Workspace& ws, hipStream_t stream);
+void launch_close_count(const Frame& f, Workspace& ws, hipStream_t stream);
+void launch_close_fill(const Frame& f, Workspace& ws, hipStream_t stream);
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* tmp, uint64_t* out, unsigned long long* total, hipStream_t stream);
+void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
+void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                       hipStream_t stream);
 void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,
                         hipEvent_t ev_join, hipEvent_t* timing /* [0..1] phase A, [2..3] phase B */);
 void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);

@@ -108,7 +108,7 @@ static __device__ __forceinline__ Earth earth_for(const Frame& f) {
 // ---------------------------------------------------------------------------------------------
 // set-up: Altitude::abs for the observer and every object (params.rs:23-30, object/mod.rs:166-175)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_resolve(Frame f, double* alt, ObjectDev* objects, const atmrt_position_t* obj_pos) {
+__global__ void k_resolve(Frame f, double* alt, ObjectDev* objects) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
     const atmrt_position_t& pos = f.p.position;
@@ -116,11 +116,12 @@ __global__ void k_resolve(Frame f, double* alt, ObjectDev* objects, const atmrt_
                ? pos.altitude
                : terrain_elev_or_zero(f.tv, pos.latitude, pos.longitude) + pos.altitude;
   }
-  if (i < f.n_objects) {
-    const atmrt_position_t pos = obj_pos[i];
-    objects[i].elev = pos.altitude_kind == ATMRT_ALT_ABSOLUTE
-                          ? pos.altitude
-                          : terrain_elev_or_zero(f.tv, pos.latitude, pos.longitude) + pos.altitude;
+  if (i < f.n_objects) { // the host stores the altitude kind in _pad and the configured altitude in elev
+    ObjectDev o = objects[i];
+    if (o._pad == ATMRT_ALT_RELATIVE) o.elev = terrain_elev_or_zero(f.tv, o.lat, o.lon) + o.elev;
+    o._pad = ATMRT_ALT_ABSOLUTE;
+    object_derive(f.earth, f.p.simulation_step, o);
+    objects[i] = o;
   }
 }
 
@@ -139,9 +140,10 @@ __global__ void k_fast_columns(Frame f, DirCalc* colcalc) {
 // Phase A.  A wavefront covers 64 adjacent columns at one sample index, so its profile store is one
 // coalesced 512-byte row segment and its terrain gathers fall on neighbouring posts of the mosaic.
 constexpr int PROFILE_SAMPLES_PER_BLOCK = 16;
-template <int CALC>
+template <int CALC, bool STORE_LL>
 __global__ __launch_bounds__(256) void k_terrain_profile(Frame f, const DirCalc* __restrict__ colcalc,
-                                                         double* __restrict__ prof) {
+                                                         double* __restrict__ prof, double* __restrict__ plat,
+                                                         double* __restrict__ plon) {
   int x = blockIdx.x * 64 + (threadIdx.x & 63);
   int sub = threadIdx.x >> 6;
   if (x >= f.wl) return;
@@ -154,6 +156,10 @@ __global__ __launch_bounds__(256) void k_terrain_profile(Frame f, const DirCalc*
     double lat, lon;
     coords_at_dist(e, c, f.xs[i], lat, lon);
     prof[(size_t)i * f.wl + x] = terrain_elev_or_zero(f.tv, lat, lon);
+    if (STORE_LL) {
+      plat[(size_t)i * f.wl + x] = lat;
+      plon[(size_t)i * f.wl + x] = lon;
+    }
   }
 }
 
@@ -355,6 +361,7 @@ __global__ __launch_bounds__(256) void k_fast_finalize_list(Frame f, uint64_t n_
                                                             const uint32_t* __restrict__ list_pixel, PackedHits packed) {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_hits) return;
+  if (f.n_objects && packed.color_tag[k] != ATMRT_COLOR_TERRAIN) return; // object points are already complete
   uint32_t p = list_pixel[k];
   int x = (int)(p % (uint32_t)f.wl), y = (int)(p / (uint32_t)f.wl);
   const DirCalc c = colcalc[x];
@@ -528,10 +535,302 @@ __global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_
                                                             PackedHits packed) {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_hits) return;
+  if (f.n_objects && packed.color_tag[k] != ATMRT_COLOR_TERRAIN) return; // object points are already complete
   uint32_t p = list_pixel[k];
   int x = (int)(p % (uint32_t)f.wl), y = (int)(p / (uint32_t)f.wl);
   store_packed(packed, k, rect_hit<CALC>(f, x, y, (int)list_step[k], rec.re0[k], rec.pl0[k], rec.re1[k], rec.pl1[k]),
                f.p.terrain_alpha);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// General tracer: scenes with objects (and any terrain_alpha).  get_single_pixel in full
+// (utils.rs:201-289): per step the terrain sign change plus the collisions with every object that is
+// close to either sample, stable-sorted by prop; stop after the step if anything opaque was hit.
+// Two passes (count -> exclusive scan -> fill) because the trace-point lists have variable length.
+// ---------------------------------------------------------------------------------------------
+constexpr int STEP_CANDIDATES = 12; // trace points one step may produce here (terrain + 4 per object); more sets the error flag
+constexpr int CLOSE_CAP = 8;        // Rectilinear: objects close to one sample kept per lane; more sets the error flag
+
+struct StepHits {
+  int n;
+  bool finish;
+  int kind[STEP_CANDIDATES]; // -1 terrain, else object index
+  Collision col[STEP_CANDIDATES];
+};
+
+static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int kind, const Collision* c,
+                                                 unsigned long long* counters) {
+  if (sh.n >= STEP_CANDIDATES) {
+    atomicOr(&counters[2], 1ull);
+    return;
+  }
+  int j = sh.n; // step_result.sort_by(prop) is stable: insert behind every element with prop <= new prop
+  while (j > 0 && sh.col[j - 1].prop > prop) {
+    sh.col[j] = sh.col[j - 1];
+    sh.kind[j] = sh.kind[j - 1];
+    j--;
+  }
+  sh.kind[j] = kind;
+  sh.col[j].prop = prop;
+  if (c) {
+    sh.col[j].normal = c->normal;
+    for (int q = 0; q < 4; q++) sh.col[j].color[q] = c->color[q];
+  }
+  sh.n++;
+}
+
+// collisions of one object with the segment, utils.rs:251-278
+static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2,
+                                                   unsigned long long* counters) {
+  Collision col[4];
+  int nc = object_collision(f.objects[idx], f.textures, pos1, pos2, col);
+  for (int q = 0; q < nc; q++) {
+    if (col[q].color[3] == 0.0) continue;
+    step_push(sh, col[q].prop, idx, &col[q], counters);
+    if (col[q].color[3] == 1.0) {
+      sh.finish = true;
+      break;
+    }
+  }
+}
+
+// emit the sorted trace points of one step (fill pass).  Terrain points are finished later by the
+// *_finalize_list kernels (they need find_normal); object points are complete here (utils.rs:261-272).
+static __device__ __forceinline__ void step_emit(const StepHits& sh, const PackedHits& packed, uint32_t* list_step,
+                                                 uint32_t* list_pixel, uint64_t& k, uint32_t pixel, int step_index,
+                                                 double lat0, double lon0, double re0, double d0, double pl0, double lat1,
+                                                 double lon1, double re1, double d1, double pl1) {
+  for (int j = 0; j < sh.n; j++, k++) {
+    list_step[k] = (uint32_t)step_index;
+    list_pixel[k] = pixel;
+    if (sh.kind[j] < 0) {
+      packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
+      continue;
+    }
+    double prop = sh.col[j].prop;
+    packed.lat[k] = lerp_ts(lat0, lat1, prop);
+    packed.lon[k] = lerp_ts(lon0, lon1, prop);
+    packed.distance[k] = lerp_ts(d0, d1, prop);
+    packed.elevation[k] = lerp_ts(re0, re1, prop); // object hits report the RAY elevation (utils.rs:268)
+    packed.path_length[k] = lerp_ts(pl0, pl1, prop);
+    packed.normal[3 * k] = sh.col[j].normal.x;
+    packed.normal[3 * k + 1] = sh.col[j].normal.y;
+    packed.normal[3 * k + 2] = sh.col[j].normal.z;
+    packed.color_tag[k] = ATMRT_COLOR_RGBA;
+    for (int q = 0; q < 4; q++) packed.rgba[4 * k + q] = sh.col[j].color[q];
+  }
+}
+
+// Fast, phase A extras: which objects are close to each terrain sample (TerrainData::from_lat_lon, utils.rs:74-80)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_close_objects(Frame f, const double* __restrict__ plat,
+                                                       const double* __restrict__ plon, uint32_t* __restrict__ ccount,
+                                                       const uint64_t* __restrict__ coffset, uint32_t* __restrict__ clist) {
+  size_t n = (size_t)f.n_t * f.wl;
+  size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const LatLonTrig t = latlon_trig(f.earth, plat[s], plon[s]);
+  uint32_t c = 0;
+  uint64_t k = FILL ? coffset[s] : 0;
+  for (int j = 0; j < f.n_objects; j++) {
+    if (object_is_close(f.earth, f.objects[j], t)) {
+      if (FILL) clist[k + c] = (uint32_t)j;
+      c++;
+    }
+  }
+  if (!FILL) ccount[s] = c;
+}
+
+// Fast, phase C, general.  One pixel per lane (x fastest: every load of the sample-major caches is coalesced).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __restrict__ prof,
+                                                    const double* __restrict__ plat, const double* __restrict__ plon,
+                                                    const uint32_t* __restrict__ ccount,
+                                                    const uint64_t* __restrict__ coffset,
+                                                    const uint32_t* __restrict__ clist, const double* __restrict__ pelev,
+                                                    const double* __restrict__ plen, const int32_t* __restrict__ npath,
+                                                    uint32_t* __restrict__ hit_count,
+                                                    const uint64_t* __restrict__ hit_offset, PackedHits packed,
+                                                    uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                    unsigned long long* __restrict__ counters) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  unsigned long long steps = 0;
+  if (x < f.wl) {
+    int n = npath[y];
+    n = n < f.n_t ? n : f.n_t;
+    const size_t p = (size_t)y * f.wl + x;
+    const double* row = pelev + (size_t)y * f.n_path_cap;
+    const double* lrow = plen + (size_t)y * f.n_path_cap;
+    const bool terrain_opaque = f.p.terrain_alpha == 1.0;
+    uint64_t k = FILL ? hit_offset[p] : 0;
+    unsigned count = 0;
+    double te0 = prof[x], re0 = row[0];
+    uint32_t c0 = ccount[x];
+    for (int i = 1; i < n; i++) {
+      size_t s1 = (size_t)i * f.wl + x, s0 = s1 - f.wl;
+      double te1 = prof[s1], re1 = row[i];
+      uint32_t c1 = ccount[s1];
+      StepHits sh;
+      sh.n = 0;
+      sh.finish = false;
+      steps++;
+      double diff1 = re0 - te0, diff2 = re1 - te1;
+      if (diff1 * diff2 < 0.0) { // utils.rs:222-240
+        step_push(sh, diff1 / (diff1 - diff2), -1, nullptr, counters);
+        if (terrain_opaque) sh.finish = true;
+      }
+      if (c0 | c1) { // utils.rs:241-280, union in ascending index order
+        double lat0 = plat[s0], lon0 = plon[s0], lat1 = plat[s1], lon1 = plon[s1];
+        Vec3 pos1 = as_cartesian(f.earth, lat0, lon0, re0), pos2 = as_cartesian(f.earth, lat1, lon1, re1);
+        const uint32_t* la = clist + coffset[s0];
+        const uint32_t* lb = clist + coffset[s1];
+        uint32_t ia = 0, ib = 0;
+        while (ia < c0 || ib < c1) {
+          uint32_t idx;
+          if (ib >= c1 || (ia < c0 && la[ia] <= lb[ib])) {
+            idx = la[ia];
+            if (ib < c1 && lb[ib] == idx) ib++;
+            ia++;
+          } else {
+            idx = lb[ib++];
+          }
+          step_object(sh, f, (int)idx, pos1, pos2, counters);
+        }
+        if (FILL && sh.n)
+          step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, i == 1 ? 0.0 : f.xs[i - 1],
+                    i == 1 ? 0.0 : lrow[i - 1], lat1, lon1, re1, f.xs[i], lrow[i]);
+      } else if (FILL && sh.n) { // terrain only: the finalize kernel recomputes the geodesic points
+        step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, 0.0, 0.0, re0, 0.0, 0.0, 0.0, 0.0, re1, 0.0, 0.0);
+      }
+      count += (unsigned)sh.n;
+      if (sh.finish) break;
+      te0 = te1;
+      re0 = re1;
+      c0 = c1;
+    }
+    if (!FILL) hit_count[p] = count;
+  }
+  if (!FILL) {
+    steps = wave_sum(steps);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+  }
+}
+
+// Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter over all objects
+// (TerrainData::from_lat_lon, utils.rs:72-88), then the step logic above.
+template <bool FILL, int CALC>
+__global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
+                                                    PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
+                                                    uint32_t* __restrict__ list_pixel,
+                                                    unsigned long long* __restrict__ counters) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long steps = 0;
+  if (p < plane) {
+    const Earth e = earth_for<CALC>(f);
+    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+    const bool sph = e.spherical != 0;
+    const double radius = e.shape_radius;
+    const bool straight = f.p.straight_rays != 0;
+    const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+    const bool terrain_opaque = f.p.terrain_alpha == 1.0;
+    const double alt = *f.alt;
+    double direction, elevation;
+    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+    DirCalc c;
+    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+    Stepper s;
+    stepper_init(s, sph, radius, alt, elevation);
+    unsigned count = 0;
+    uint64_t k = FILL ? hit_offset[p] : 0;
+    if (!(0.0 > max_dist || alt < -1000.0)) {
+      double lat0, lon0;
+      coords_at_dist(e, c, 0.0, lat0, lon0);
+      double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
+      int ids0[CLOSE_CAP], ids1[CLOSE_CAP];
+      int n0 = 0, n1 = 0;
+      {
+        const LatLonTrig t = latlon_trig(e, lat0, lon0);
+        for (int j = 0; j < f.n_objects; j++)
+          if (object_is_close(e, f.objects[j], t)) {
+            if (n0 < CLOSE_CAP) ids0[n0++] = j;
+            else atomicOr(&counters[2], 2ull);
+          }
+      }
+      double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
+      double sx = 0.0, sh_ = alt, path_length = 0.0;
+      for (int i = 1;; i++) {
+        RayState st = stepper_next(s, f.atm, sph, radius, straight, step);
+        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h);
+        sx = st.x;
+        sh_ = st.h;
+        if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
+        double lat1, lon1;
+        coords_at_dist(e, c, sx, lat1, lon1);
+        double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
+        n1 = 0;
+        {
+          const LatLonTrig t = latlon_trig(e, lat1, lon1);
+          for (int j = 0; j < f.n_objects; j++)
+            if (object_is_close(e, f.objects[j], t)) {
+              if (n1 < CLOSE_CAP) ids1[n1++] = j;
+              else atomicOr(&counters[2], 2ull);
+            }
+        }
+        steps++;
+        StepHits hits;
+        hits.n = 0;
+        hits.finish = false;
+        double diff1 = re0 - te0, diff2 = sh_ - te1;
+        if (diff1 * diff2 < 0.0) {
+          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr, counters);
+          if (terrain_opaque) hits.finish = true;
+        }
+        if (n0 | n1) {
+          Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
+          int ia = 0, ib = 0;
+          while (ia < n0 || ib < n1) {
+            int idx;
+            if (ib >= n1 || (ia < n0 && ids0[ia] <= ids1[ib])) {
+              idx = ids0[ia];
+              if (ib < n1 && ids1[ib] == idx) ib++;
+              ia++;
+            } else {
+              idx = ids1[ib++];
+            }
+            step_object(hits, f, idx, pos1, pos2, counters);
+          }
+        }
+        if (FILL && hits.n) {
+          uint64_t k0 = k;
+          step_emit(hits, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx,
+                    path_length);
+          for (uint64_t q = k0; q < k; q++) { // terrain points: what k_rect_finalize_list needs
+            rec.re0[q] = re0;
+            rec.pl0[q] = pl0;
+            rec.re1[q] = sh_;
+            rec.pl1[q] = path_length;
+          }
+        }
+        count += (unsigned)hits.n;
+        if (hits.finish) break;
+        lat0 = lat1; lon0 = lon1; te0 = te1; re0 = sh_; d0 = sx; pl0 = path_length;
+        n0 = n1;
+        for (int q = 0; q < CLOSE_CAP; q++) ids0[q] = ids1[q];
+      }
+    }
+    if (!FILL) {
+      out.azimuth[p] = dm_to_degrees(direction);
+      out.elevation_angle[p] = dm_to_degrees(elevation);
+      out.hit_count[p] = count;
+    }
+  }
+  if (!FILL) {
+    steps = wave_sum(steps);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -665,9 +964,7 @@ __global__ void k_coords_at_dist(Frame f, double lat0, double lon0, double dir, 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 void launch_resolve(const Frame& f, Workspace& ws, ObjectDev* objects_mut, hipStream_t stream) {
-  (void)objects_mut;
-  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, stream, f, ws.alt, (ObjectDev*)nullptr,
-                     (const atmrt_position_t*)nullptr);
+  hipLaunchKernelGGL(k_resolve, dim3(cdiv((size_t)f.n_objects + 1, 64)), dim3(64), 0, stream, f, ws.alt, objects_mut);
 }
 
 constexpr int FAST_RR = 8;
@@ -683,9 +980,15 @@ void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipSt
   (void)hipEventRecord(ev_join, stream2);
   (void)hipEventRecord(timing[0], stream);
   hipLaunchKernelGGL(k_fast_columns, dim3(cdiv(f.wl, 256)), dim3(256), 0, stream, f, ws.colcalc);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC>),
-                                                        dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)),
-                                                        dim3(256), 0, stream, f, ws.colcalc, ws.prof));
+  if (f.n_objects) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC, true>),
+                                                          dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)),
+                                                          dim3(256), 0, stream, f, ws.colcalc, ws.prof, ws.plat, ws.plon));
+  } else {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC, false>),
+                                                          dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)),
+                                                          dim3(256), 0, stream, f, ws.colcalc, ws.prof, ws.plat, ws.plon));
+  }
   (void)hipEventRecord(timing[1], stream);
   (void)hipStreamWaitEvent(stream, ev_join, 0);
 }
@@ -734,13 +1037,73 @@ void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hi
   }
 }
 
-void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count, hipStream_t stream) {
-  size_t n = (size_t)f.wl * f.h;
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* tmp, uint64_t* out, unsigned long long* total,
+                     hipStream_t stream) {
   unsigned nb = cdiv(n, 256 * SCAN_ITEMS);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, hit_count, n, ws.scan_tmp);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, ws.scan_tmp, (size_t)nb,
-                     (unsigned long long*)ws.counters);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, hit_count, n, ws.scan_tmp, ws.hit_offset);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, stream, in, n, tmp);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, tmp, (size_t)nb, total);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, stream, in, n, tmp, out);
+}
+
+void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count, hipStream_t stream) {
+  launch_scan_u32(hit_count, (size_t)f.wl * f.h, ws.scan_tmp, ws.hit_offset, (unsigned long long*)ws.counters, stream);
+}
+
+void launch_close_count(const Frame& f, Workspace& ws, hipStream_t stream) {
+  size_t n = (size_t)f.n_t * f.wl;
+  hipLaunchKernelGGL((k_close_objects<false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.ccount,
+                     (const uint64_t*)nullptr, (uint32_t*)nullptr);
+  // total number of list entries -> counters[3]
+  launch_scan_u32(ws.ccount, n, ws.scan_tmp, ws.coffset, (unsigned long long*)ws.counters + 2, stream);
+}
+
+void launch_close_fill(const Frame& f, Workspace& ws, hipStream_t stream) {
+  size_t n = (size_t)f.n_t * f.wl;
+  hipLaunchKernelGGL((k_close_objects<true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.ccount,
+                     ws.coffset, ws.clist);
+}
+
+void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  PackedHits none = {};
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
+    size_t n = (size_t)f.wl * f.h;
+    RectRec rec = {};
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, out, (const uint64_t*)nullptr, none, rec, (uint32_t*)nullptr,
+                                                          (uint32_t*)nullptr, (unsigned long long*)ws.counters));
+  } else {
+    hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
+                       ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, out.hit_count, (const uint64_t*)nullptr,
+                       none, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
+  }
+}
+
+void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                       hipStream_t stream) {
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
+    size_t n = (size_t)f.wl * f.h;
+    RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, dense, ws.hit_offset, packed, rec, ws.list_step, ws.list_pixel,
+                                                          (unsigned long long*)ws.counters));
+    if (n_hits) {
+      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                            stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));
+    }
+    hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
+                       dense, 0);
+  } else {
+    hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
+                       ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, dense.hit_count, ws.hit_offset, packed,
+                       ws.list_step, ws.list_pixel, (unsigned long long*)ws.counters);
+    if (n_hits) {
+      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                            stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,
+                                                            ws.list_step, ws.list_pixel, packed));
+    }
+    hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
+                       dense, 1);
+  }
 }
 
 void launch_pack_first_hits(const Frame& f, Workspace& ws, const DensePlanes& dense, const PackedHits& packed,

@@ -115,3 +115,58 @@ def scene(name, width=None, height=None, generator="Fast", step=None, level=1, *
     cfg = Config.from_dict(d)
     tiles = synth_tiles(*b["tiles"], level=level) if b["tiles"] else {}
     return cfg, tiles
+
+
+def checker_texture(n=64, seed=4321):
+    """64x64 RGBA checker with a transparent border ring and a translucent band (exercises alpha 0 / partial / 1)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:n, 0:n]
+    tex = np.zeros((n, n, 4), dtype=np.uint8)
+    cell = ((xx // 8) + (yy // 8)) % 2
+    tex[..., 0] = np.where(cell, 230, 40)
+    tex[..., 1] = np.where(cell, 200, 60) + rng.integers(0, 20, (n, n))
+    tex[..., 2] = np.where(cell, 30, 180)
+    tex[..., 3] = 255
+    tex[n // 2 - 4:n // 2 + 4, :, 3] = 128   # translucent band
+    tex[:3, :, 3] = 0                        # fully transparent ring: skipped trace points (utils.rs:258-260)
+    tex[-3:, :, 3] = 0
+    tex[:, :3, 3] = 0
+    tex[:, -3:, 3] = 0
+    return np.ascontiguousarray(tex)
+
+
+def add_objects(cfg, n_cyl=700, n_bill=300, seed=4321, dist=(1_000.0, 150_000.0), spread_deg=60.0, radius=(5.0, 50.0),
+                height=(20.0, 200.0), bill_w=(20.0, 200.0), bill_h=(10.0, 100.0)):
+    """Scene S5 of SURVEY.md §8(d): objects placed by default_rng(seed) uniformly in azimuth (direction +- spread)
+    and distance from the observer, on the terrain (Relative 0)."""
+    import ctypes as C
+    rng = np.random.default_rng(seed)
+    p = cfg.params
+    lat0, lon0 = np.radians(p.position.latitude), np.radians(p.position.longitude)
+    R = 6371000.0
+    tex = checker_texture()
+    cfg._keepalive.append(tex)
+    objs = []
+    for i in range(n_cyl + n_bill):
+        az = np.radians(p.frame.direction + rng.uniform(-spread_deg, spread_deg))
+        s = rng.uniform(*dist) / R
+        lat = np.arcsin(np.sin(lat0) * np.cos(s) + np.cos(lat0) * np.sin(s) * np.cos(az))
+        lon = lon0 + np.arctan2(np.sin(az) * np.sin(s) * np.cos(lat0), np.cos(s) - np.sin(lat0) * np.sin(lat))
+        o = _abi.Object()
+        o.position.latitude, o.position.longitude = float(np.degrees(lat)), float(np.degrees(lon))
+        o.position.altitude_kind, o.position.altitude = _abi.ALT_RELATIVE, 0.0
+        if i < n_cyl:
+            kind = i % 3  # cylinder, cone, frustum
+            r = float(rng.uniform(*radius))
+            o.kind, o.r1, o.height = _abi.OBJ_FRUSTUM, r, float(rng.uniform(*height))
+            o.r2 = r if kind == 0 else 0.0 if kind == 1 else 0.4 * r
+            col = rng.uniform(0.0, 1.0, 3)
+            o.color[0], o.color[1], o.color[2] = (float(v) for v in col)
+            o.color[3] = 1.0 if rng.uniform() < 0.5 else 0.5
+        else:
+            o.kind, o.width, o.height = _abi.OBJ_BILLBOARD, float(rng.uniform(*bill_w)), float(rng.uniform(*bill_h))
+            o.texture_rgba = tex.ctypes.data_as(C.POINTER(C.c_uint8))
+            o.texture_width = o.texture_height = tex.shape[0]
+        objs.append(o)
+    cfg.objects = objs
+    return cfg

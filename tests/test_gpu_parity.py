@@ -135,3 +135,26 @@ def test_full_size_properties(gpu_ctx):
     for k in ("hit_count", "lat", "lon", "distance", "elevation"):
         assert np.array_equal(a[k], b[k])
     assert a["ray_steps"] == b["ray_steps"] > 0
+
+
+def _object_scene(generator, w, h, alpha=1.0, **kw):
+    cfg, tiles = synth.scene("S2", w, h, generator=generator, terrain_alpha=alpha, max_distance=30_000.0, tilt=-2.0, **kw)
+    synth.add_objects(cfg, n_cyl=40, n_bill=24, dist=(300.0, 6_000.0), spread_deg=28.0, radius=(30.0, 120.0), height=(150.0, 600.0),
+                      bill_w=(150.0, 500.0), bill_h=(150.0, 500.0))
+    return cfg, tiles
+
+
+@pytest.mark.parametrize("generator,w,h", [("Fast", 96, 48), ("Rectilinear", 48, 24)])
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_scene_objects(gpu_ctx, oracle_det, generator, w, h, alpha):
+    """BASELINE config 5 (reduced): cylinders / cones / frusta / textured billboards, opaque and translucent, with opaque
+    and translucent terrain — the full get_single_pixel (utils.rs:201-289) incl. per-step sorting and early termination."""
+    cfg, tiles = _object_scene(generator, w, h, alpha)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert (got["color_tag"] == 1).sum() > 20, "the scene must produce object hits"
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
+def test_scene_objects_flat_earth(gpu_ctx, oracle_det):
+    cfg, tiles = _object_scene("Fast", 64, 32, 0.5, earth_shape="FlatDistorted")
+    assert_bitexact(run_gpu(gpu_ctx, cfg, tiles), run_oracle(oracle_det, cfg, tiles))

@@ -3,6 +3,7 @@
 // without a HIP device atmrt_ctx_create fails with ATMRT_ERR_NO_DEVICE.
 #include <dirent.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -84,7 +85,7 @@ struct atmrt_ctx {
   // workspace
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
-      d_ccount, d_coffset, d_clist;
+      d_ccount, d_coffset, d_clist, d_px_steps, d_interp, d_lat_dense, d_lat_packed, d_lat_offset;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -255,7 +256,8 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
   for (DevBuf* b : {&c->d_posts, &c->d_tiles, &c->d_cells, &c->d_xs, &c->d_alt, &c->d_colcalc, &c->d_prof, &c->d_pelev,
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
-                    &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_dense, &c->d_packed, &c->d_io})
+                    &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
+                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io})
     b->release();
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -549,6 +551,9 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   f.wl = (p.col_begin == 0 && p.col_end == 0) ? p.width : p.col_end - p.col_begin;
   f.h = p.height;
   f.opaque = (p.terrain_alpha == 1.0 && c->objects.empty()) ? 1 : 0;
+  f.lattice = 0;
+  f.di0 = f.ei0 = 0;
+  f.dir_step = f.elev_step = 0.0;
   *out = f;
   return ATMRT_OK;
 }
@@ -571,6 +576,7 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->ccount = c->d_ccount.as<uint32_t>();
   ws->coffset = c->d_coffset.as<uint64_t>();
   ws->clist = c->d_clist.as<uint32_t>();
+  ws->px_steps = nullptr;
   if (f.p.generator != ATMRT_GEN_RECTILINEAR) {
     HIP_TRY(c, c->d_colcalc.reserve((size_t)f.wl * sizeof(DirCalc)));
     HIP_TRY(c, c->d_prof.reserve((size_t)f.n_t * f.wl * sizeof(double)));
@@ -636,15 +642,12 @@ static PackedHits carve_packed(void* base, size_t n) {
 }
 static size_t packed_bytes(size_t n) { return n * (5 * 8 + 24 + 32 + 4) + 8 * 256 + 256; }
 
-// Runs the generator named in params.  `dense` must be device memory.  When `want_packed`, the
-// packed trace points are left in c->d_packed (n_hits of them).
-static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlanes& dense, bool want_packed,
-                         PackedHits* packed_out, uint64_t* n_hits_out, uint64_t* ray_steps_out, double* ms_out) {
-  if (f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR)
-    return c->fail(ATMRT_ERR_UNSUPPORTED, "InterpolatingRectilinear is not implemented on the device yet");
+// One frame of the Fast or Rectilinear generator into `dense` (device memory).  When `want_packed` (or whenever
+// a pixel can hold several trace points) the packed trace points are left in c->d_packed and their offsets in
+// ws.hit_offset.  Counters are NOT reset here.
+static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlanes& dense, bool want_packed,
+                    PackedHits* packed_out, uint64_t* n_hits_out) {
   hipStream_t s = c->stream;
-  HIP_TRY(c, hipEventRecord(c->ev_t0, s));
-  HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint64_t), s));
   launch_resolve(f, ws, c->d_objects.as<ObjectDev>(), s);
   // phase events: [0..1] profile, [2..3] paths (stream2), [4..5] intersect / march, [5..6] finalize, [7..8] pack
   hipEvent_t* ev = c->ev;
@@ -681,9 +684,9 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     HIP_TRY(c, hipEventRecord(ev[6], s));
   }
   HIP_TRY(c, hipEventRecord(ev[7], s));
-  uint64_t counters[4] = {0, 0, 0, 0};
   PackedHits packed{};
   if (want_packed || !f.opaque) {
+    uint64_t counters[4] = {0, 0, 0, 0};
     launch_scan_counts(f, ws, dense.hit_count, s);
     HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -709,9 +712,137 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
         launch_multi_fill_fast(f, ws, n_hits, dense, packed, s);
       }
     }
-    *n_hits_out = n_hits;
+    if (n_hits_out) *n_hits_out = n_hits;
   }
   HIP_TRY(c, hipEventRecord(ev[8], s));
+  if (packed_out) *packed_out = packed;
+  return ATMRT_OK;
+}
+
+static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws);
+
+// InterpolatingRectilinearGenerator::generate (interpolating_rectilinear.rs:110-162): ray table -> lattice steps ->
+// lattice frame through the Fast pipeline -> 4-corner blend (count -> scan -> fill).
+static int run_interpolating(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlanes& dense, PackedHits* packed_out,
+                             uint64_t* n_hits_out) {
+  hipStream_t s = c->stream;
+  const size_t W = f.p.width, H = f.p.height, npx = (size_t)f.wl * f.h;
+  // gen_fov_data :453-522
+  size_t bytes = 2 * W * H * 8 + (W + H) * 8 + npx * (4 + 4 + 8 + 8) + 64 + 4096;
+  HIP_TRY(c, c->d_interp.reserve(bytes));
+  InterpBuffers ib{};
+  {
+    char* p = c->d_interp.as<char>();
+    auto take = [&](size_t b) {
+      void* r = p;
+      p += (b + 255) / 256 * 256;
+      return r;
+    };
+    HIP_TRY(c, c->d_interp.reserve(bytes + 16 * 256));
+    p = c->d_interp.as<char>();
+    ib.dir = (double*)take(W * H * 8);
+    ib.elev = (double*)take(W * H * 8);
+    ib.colmin = (double*)take(W * 8);
+    ib.rowmin = (double*)take(H * 8);
+    ib.rem_e = (double*)take(npx * 8);
+    ib.rem_d = (double*)take(npx * 8);
+    ib.key_e = (int32_t*)take(npx * 4);
+    ib.key_d = (int32_t*)take(npx * 4);
+    ib.bounds = (int32_t*)take(16);
+  }
+  launch_fov_table(f, ib, s);
+  std::vector<double> mins(W + H);
+  HIP_TRY(c, hipMemcpyAsync(mins.data(), ib.colmin, W * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(mins.data() + W, ib.rowmin, H * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  double min_elev_step = INFINITY, min_dir_step = INFINITY; // .reduce(|| INFINITY, f64::min) * SCALE
+  for (size_t x = 0; x < W; x++) min_elev_step = std::fmin(min_elev_step, mins[x]);
+  for (size_t y = 0; y < H; y++) min_dir_step = std::fmin(min_dir_step, mins[W + y]);
+  min_elev_step *= 1.5;
+  min_dir_step *= 1.5;
+  if (!(min_elev_step > 0.0) || !(min_dir_step > 0.0) || !std::isfinite(min_elev_step) || !std::isfinite(min_dir_step))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "degenerate field of view for InterpolatingRectilinear");
+  int32_t bounds[4] = {INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
+  HIP_TRY(c, hipMemcpyAsync(ib.bounds, bounds, sizeof bounds, hipMemcpyHostToDevice, s));
+  launch_lattice_keys(f, ib, min_elev_step, min_dir_step, s);
+  HIP_TRY(c, hipMemcpyAsync(bounds, ib.bounds, sizeof bounds, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  const int64_t ne = (int64_t)bounds[1] + 1 - bounds[0] + 1, nd = (int64_t)bounds[3] + 1 - bounds[2] + 1;
+  if (ne <= 0 || nd <= 0 || ne > 60000 || nd > 2000000 || ne * nd > (int64_t)1 << 31)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "InterpolatingRectilinear lattice of %lld x %lld points is out of range",
+                   (long long)nd, (long long)ne);
+  // the lattice frame (Cache::get_pixel :80-107 for every lattice point of the bounding rectangle)
+  Frame fl = f;
+  fl.p.generator = ATMRT_GEN_FAST;
+  fl.lattice = 1;
+  fl.di0 = bounds[2];
+  fl.ei0 = bounds[0];
+  fl.dir_step = min_dir_step;
+  fl.elev_step = min_elev_step;
+  fl.c0 = 0;
+  fl.wl = (int32_t)nd;
+  fl.h = (int32_t)ne;
+  const size_t nlat = (size_t)nd * ne;
+  Workspace wsl{};
+  int rc = prepare_workspace(c, fl, &wsl);
+  if (rc) return rc;
+  HIP_TRY(c, c->d_px_steps.reserve(nlat * 4 + nlat + 256));
+  wsl.px_steps = c->d_px_steps.as<uint32_t>();
+  ib.referenced = reinterpret_cast<uint8_t*>(wsl.px_steps + nlat);
+  HIP_TRY(c, hipMemsetAsync(ib.referenced, 0, nlat, s));
+  HIP_TRY(c, c->d_lat_dense.reserve(dense_bytes(nlat)));
+  DensePlanes ldense = carve_dense(c->d_lat_dense.ptr, nlat);
+  PackedHits lpacked{};
+  uint64_t lhits = 0;
+  if ((rc = run_core(c, fl, wsl, ldense, true, &lpacked, &lhits))) return rc;
+  std::swap(c->d_packed, c->d_lat_packed);   // keep the lattice result; the image gets fresh buffers
+  std::swap(c->d_hit_offset, c->d_lat_offset);
+  LatticeResult lr{};
+  lr.hit_count = ldense.hit_count;
+  lr.hit_offset = c->d_lat_offset.as<uint64_t>();
+  lr.azimuth = ldense.azimuth;
+  lr.elevation_angle = ldense.elevation_angle;
+  lr.hits = lpacked;
+  lr.px_steps = wsl.px_steps;
+  lr.nd = (int32_t)nd;
+  lr.ne = (int32_t)ne;
+  // blend: count -> scan -> fill
+  if ((rc = prepare_workspace(c, f, &ws))) return rc;
+  HIP_TRY(c, hipMemsetAsync(ws.counters, 0, sizeof(uint64_t), s)); // ray-steps: only referenced lattice pixels count
+  PackedHits none{};
+  Frame fb = f;
+  fb.di0 = fl.di0;
+  fb.ei0 = fl.ei0;
+  launch_interp_blend(fb, ws, ib, lr, false, dense, none, s);
+  launch_scan_counts(f, ws, dense.hit_count, s);
+  uint64_t counters[4] = {0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  uint64_t n_hits = counters[1];
+  HIP_TRY(c, c->d_packed.reserve(packed_bytes(n_hits)));
+  PackedHits packed = carve_packed(c->d_packed.ptr, n_hits);
+  launch_interp_blend(fb, ws, ib, lr, true, dense, packed, s);
+  launch_interp_finish(f, ws, ib, lr, dense, packed, s);
+  if (packed_out) *packed_out = packed;
+  if (n_hits_out) *n_hits_out = n_hits;
+  return ATMRT_OK;
+}
+
+// Runs the generator named in params.  `dense` must be device memory.  When `want_packed`, the
+// packed trace points are left in c->d_packed (n_hits of them).
+static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlanes& dense, bool want_packed,
+                         PackedHits* packed_out, uint64_t* n_hits_out, uint64_t* ray_steps_out, double* ms_out) {
+  hipStream_t s = c->stream;
+  hipEvent_t* ev = c->ev;
+  const bool fast = f.p.generator == ATMRT_GEN_FAST;
+  HIP_TRY(c, hipEventRecord(c->ev_t0, s));
+  HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint64_t), s));
+  PackedHits packed{};
+  int rc;
+  if (f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR) rc = run_interpolating(c, f, ws, dense, &packed, n_hits_out);
+  else rc = run_core(c, f, ws, dense, want_packed, &packed, n_hits_out);
+  if (rc) return rc;
+  uint64_t counters[4] = {0, 0, 0, 0};
   HIP_TRY(c, hipEventRecord(c->ev_t1, s));
   HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -722,7 +853,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     atmrt_timings_t t{};
     float v = 0.f;
     t.total_ms = ms;
-    if (fast) {
+    if (f.p.generator != ATMRT_GEN_RECTILINEAR) {
       HIP_TRY(c, hipEventElapsedTime(&v, ev[0], ev[1]));
       t.profile_ms = v;
       HIP_TRY(c, hipEventElapsedTime(&v, ev[2], ev[3]));
@@ -741,9 +872,11 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     t.n_hits = counters[1];
     c->timings = t;
   }
+  (void)fast;
   if (counters[2])
-    return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step or "
-                   "more than %d objects close to one sample", (unsigned long long)counters[2], 12, 8);
+    return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step, "
+                   "more than %d objects close to one sample, or more than %d trace points in four lattice corners",
+                   (unsigned long long)counters[2], 12, 8, 64);
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;

@@ -23,8 +23,26 @@ struct Frame {
   int32_t n_path_cap;       // path elements per row when the ray never drops below -1000 m
   int32_t c0, wl, h;        // pixel-column shard [c0, c0 + wl), image height
   int32_t opaque;           // terrain_alpha == 1.0 and no objects: at most one trace point per pixel
-  int32_t _pad;
+  // InterpolatingRectilinear: the frame is the angular lattice of Cache::get_pixel (interpolating_rectilinear.rs:80-107):
+  // column x has azimuth (di0 + x) * dir_step, row y has elevation (ei0 + y) * elev_step (radians)
+  int32_t lattice;
+  int32_t di0, ei0;
+  double dir_step, elev_step;
 };
+
+// column azimuth / row elevation in degrees, as handed to gen_terrain_cache / gen_path_cache
+ATMRT_HD double frame_col_dir(const Frame& f, int x) {
+  return f.lattice ? dm_to_degrees((double)(f.di0 + x) * f.dir_step) : fast_ray_dir(f.p, f.c0 + x);
+}
+ATMRT_HD double frame_row_elev(const Frame& f, int y) {
+  return f.lattice ? dm_to_degrees((double)(f.ei0 + y) * f.elev_step) : fast_ray_elev(f.p, y);
+}
+ATMRT_HD double frame_azimuth(const Frame& f, int x) { // a single wrap into [0, 360): fast.rs:67-72, interpolating_rectilinear.rs:93-98
+  double azimuth = frame_col_dir(f, x);
+  if (azimuth < 0.0) azimuth += 360.0;
+  else if (azimuth >= 360.0) azimuth -= 360.0;
+  return azimuth;
+}
 
 // Dense per-pixel outputs ([h][wl] row-major).  `normal` is planar [3][h][wl].
 struct DensePlanes {
@@ -72,7 +90,37 @@ struct Workspace {
   uint32_t* ccount;       // [n_t][wl] number of close objects
   uint64_t* coffset;      // [n_t][wl] exclusive scan of ccount
   uint32_t* clist;        // object indices, ascending per sample
+  uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
 };
+
+// InterpolatingRectilinear scratch
+struct InterpBuffers {
+  double* dir;        // [H][W] ray_params_table.direction (radians), full image
+  double* elev;       // [H][W]
+  double* colmin;     // [W]
+  double* rowmin;     // [H]
+  int32_t* key_e;     // [h][wl] elev_index of the pixel's first lattice corner
+  int32_t* key_d;     // [h][wl]
+  double* rem_e;      // [h][wl]
+  double* rem_d;      // [h][wl]
+  int32_t* bounds;    // [4] min/max of elev_index and dir_index over the shard
+  uint8_t* referenced;// [ne][nd]
+};
+struct LatticeResult { // the lattice frame's packed result
+  const uint32_t* hit_count;
+  const uint64_t* hit_offset;
+  const double* azimuth;
+  const double* elevation_angle;
+  PackedHits hits;
+  const uint32_t* px_steps;
+  int32_t nd, ne;
+};
+void launch_fov_table(const Frame& f, const InterpBuffers& ib, hipStream_t stream);
+void launch_lattice_keys(const Frame& f, const InterpBuffers& ib, double min_elev_step, double min_dir_step, hipStream_t stream);
+void launch_interp_blend(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,
+                         const DensePlanes& dense, const PackedHits& packed, hipStream_t stream);
+void launch_interp_finish(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr,
+                          const DensePlanes& dense, const PackedHits& packed, hipStream_t stream);
 
 // All launches go to `stream`; none of them synchronises or allocates.
 void launch_resolve(const Frame& f, Workspace& ws, ObjectDev* objects_mut, hipStream_t stream);

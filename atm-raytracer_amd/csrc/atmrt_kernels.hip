@@ -89,6 +89,8 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
   return v;
 }
 
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
 // The DirectionalCalc kind is a compile-time constant in the heavy kernels, so only one of the four
 // calculators (AzEq / FlDs / Spherical / Ellipsoid-Vincenty) is instantiated per kernel variant.
 template <int CALC>
@@ -131,7 +133,7 @@ __global__ void k_resolve(Frame f, double* alt, ObjectDev* objects) {
 __global__ void k_fast_columns(Frame f, DirCalc* colcalc) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= f.wl) return;
-  double dir = fast_ray_dir(f.p, f.c0 + x);
+  double dir = frame_col_dir(f, x);
   DirCalc c;
   dircalc_new(f.earth, f.p.position.latitude, f.p.position.longitude, dir, c);
   colcalc[x] = c;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
   const double alt = *f.alt;
   Stepper s;
-  stepper_init(s, sph, radius, alt, dm_to_radians(fast_ray_elev(f.p, y)));
+  stepper_init(s, sph, radius, alt, dm_to_radians(frame_row_elev(f, y)));
   size_t base = (size_t)y * f.n_path_cap;
   pelev[base] = alt;
   plen[base] = 0.0;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
                                                         const int32_t* __restrict__ npath,
                                                         int32_t* __restrict__ hit_step,
                                                         uint32_t* __restrict__ hit_count,
+                                                        uint32_t* __restrict__ px_steps,
                                                         unsigned long long* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -271,13 +274,16 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
     if (y < f.h && xok) {
       size_t p = (size_t)y * f.wl + x;
       hit_step[p] = first[r];
+      unsigned st;
       if (MODE == 0) {
         hit_count[p] = first[r] >= 0 ? 1u : 0u;
-        steps += first[r] >= 0 ? (unsigned)(first[r] + 1) : (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
+        st = first[r] >= 0 ? (unsigned)(first[r] + 1) : (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
       } else {
         hit_count[p] = cnt[r];
-        steps += (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
+        st = (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
       }
+      steps += st;
+      if (px_steps) px_steps[p] = st;
     }
   }
   steps = wave_sum(steps);
@@ -310,11 +316,8 @@ __global__ __launch_bounds__(256) void k_fast_finalize(Frame f, const DirCalc* _
   if (x >= f.wl) return;
   size_t plane = (size_t)f.wl * f.h;
   size_t p = (size_t)y * f.wl + x;
-  double azimuth = fast_ray_dir(f.p, f.c0 + x); // fast.rs:67-72: a single wrap into [0, 360)
-  if (azimuth < 0.0) azimuth += 360.0;
-  else if (azimuth >= 360.0) azimuth -= 360.0;
-  out.azimuth[p] = azimuth;
-  out.elevation_angle[p] = fast_ray_elev(f.p, y);
+  out.azimuth[p] = frame_azimuth(f, x);
+  out.elevation_angle[p] = frame_row_elev(f, y);
   int s = hit_step[p];
   if (s < 0) {
     store_dense_miss(out, p, plane);
@@ -378,11 +381,8 @@ __global__ __launch_bounds__(256) void k_dense_from_packed(Frame f, const uint64
   size_t plane = (size_t)f.wl * f.h;
   size_t p = (size_t)y * f.wl + x;
   if (fast_angles) {
-    double azimuth = fast_ray_dir(f.p, f.c0 + x);
-    if (azimuth < 0.0) azimuth += 360.0;
-    else if (azimuth >= 360.0) azimuth -= 360.0;
-    out.azimuth[p] = azimuth;
-    out.elevation_angle[p] = fast_ray_elev(f.p, y);
+    out.azimuth[p] = frame_azimuth(f, x);
+    out.elevation_angle[p] = frame_row_elev(f, y);
   }
   if (out.hit_count[p] == 0) {
     store_dense_miss(out, p, plane);
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
                                                     uint32_t* __restrict__ hit_count,
                                                     const uint64_t* __restrict__ hit_offset, PackedHits packed,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                    uint32_t* __restrict__ px_steps,
                                                     unsigned long long* __restrict__ counters) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
   int y = blockIdx.y;
@@ -710,7 +711,10 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
       re0 = re1;
       c0 = c1;
     }
-    if (!FILL) hit_count[p] = count;
+    if (!FILL) {
+      hit_count[p] = count;
+      if (px_steps) px_steps[p] = (uint32_t)steps;
+    }
   }
   if (!FILL) {
     steps = wave_sum(steps);
@@ -914,6 +918,304 @@ __global__ __launch_bounds__(256) void k_pack_first_hits(Frame f, const uint64_t
   store_packed(packed, hit_offset[p], tp, f.p.terrain_alpha);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// InterpolatingRectilinear (interpolating_rectilinear.rs): pinhole ray table -> angular lattice ->
+// the lattice frame goes through the Fast pipeline above -> 4-corner blend per pixel.
+// ---------------------------------------------------------------------------------------------
+
+// gen_fov_data :456-468: ray_params_table for the FULL image (the lattice steps are global minima)
+__global__ __launch_bounds__(256) void k_fov_table(Frame f, double* __restrict__ dir, double* __restrict__ elev) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= f.p.width) return;
+  double d, e;
+  rect_ray_params(f.p, f.ph, x, y, d, e);
+  dir[(size_t)y * f.p.width + x] = d;
+  elev[(size_t)y * f.p.width + x] = e;
+}
+// min_elev_step per column :470-491 and min_dir_step per row :493-517 (before the global min and * SCALE)
+__global__ __launch_bounds__(256) void k_fov_colmin(Frame f, const double* __restrict__ elev, double* __restrict__ colmin) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= f.p.width) return;
+  const int W = f.p.width, H = f.p.height;
+  const double min_diff = dm_to_radians(f.p.frame.fov) / (double)f.p.width / 3.0;
+  double mn = dm_to_radians(360.0), last = elev[x];
+  for (int y = 1; y < H; y++) {
+    double next = elev[(size_t)y * W + x];
+    double diff = dm_fabs(next - last);
+    if (diff < min_diff) diff = min_diff;
+    if (diff < mn) mn = diff;
+    last = next;
+  }
+  colmin[x] = mn;
+}
+__global__ __launch_bounds__(64) void k_fov_rowmin(Frame f, const double* __restrict__ dir, double* __restrict__ rowmin) {
+  int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= f.p.height) return;
+  const int W = f.p.width;
+  const double full = dm_to_radians(360.0);
+  const double min_diff = dm_to_radians(f.p.frame.fov) / (double)f.p.width / 3.0;
+  double mn = full, last = dir[(size_t)y * W];
+  for (int x = 1; x < W; x++) {
+    double next = dir[(size_t)y * W + x];
+    double diff = dm_fabs(next - last);
+    if (diff > full) diff -= full;
+    if (diff < min_diff) diff = min_diff;
+    if (diff < mn) mn = diff;
+    last = next;
+  }
+  rowmin[y] = mn;
+}
+
+static __device__ __forceinline__ int sat_i32(double v) { // Rust `f as i32`
+  if (v != v) return 0;
+  if (v <= -2147483648.0) return (int)0x80000000;
+  if (v >= 2147483647.0) return 2147483647;
+  return (int)v;
+}
+
+// FovData::cache_coords :186-204 for every pixel of the shard + bounds of the referenced lattice
+__global__ __launch_bounds__(256) void k_lattice_keys(Frame f, InterpBuffers ib, double min_elev_step, double min_dir_step) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  int ei = 0x7fffffff, di = 0x7fffffff, ej = (int)0x80000000, dj = (int)0x80000000;
+  if (x < f.wl) {
+    size_t src = (size_t)y * f.p.width + f.c0 + x, p = (size_t)y * f.wl + x;
+    double ef = ib.elev[src] / min_elev_step, df = ib.dir[src] / min_dir_step;
+    ei = ej = sat_i32(dm_floor(ef));
+    di = dj = sat_i32(dm_floor(df));
+    ib.key_e[p] = ei;
+    ib.key_d[p] = di;
+    ib.rem_e[p] = ef - (double)ei;
+    ib.rem_d[p] = df - (double)di;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    int a = __shfl_down(ei, off, 64), b = __shfl_down(di, off, 64), c = __shfl_down(ej, off, 64), d = __shfl_down(dj, off, 64);
+    ei = a < ei ? a : ei;
+    di = b < di ? b : di;
+    ej = c > ej ? c : ej;
+    dj = d > dj ? d : dj;
+  }
+  if ((threadIdx.x & 63) == 0 && ei != 0x7fffffff) {
+    atomicMin(&ib.bounds[0], ei);
+    atomicMax(&ib.bounds[1], ej);
+    atomicMin(&ib.bounds[2], di);
+    atomicMax(&ib.bounds[3], dj);
+  }
+}
+
+// TracePoint incl. colour, generators/mod.rs:21-30
+struct FullTP {
+  double lat, lon, distance, elevation, path_length;
+  Vec3 normal;
+  uint32_t tag;
+  double rgba[4];
+};
+static __device__ __forceinline__ FullTP load_tp(const PackedHits& h, uint64_t k) {
+  FullTP t;
+  t.lat = h.lat[k];
+  t.lon = h.lon[k];
+  t.distance = h.distance[k];
+  t.elevation = h.elevation[k];
+  t.path_length = h.path_length[k];
+  t.normal = v3(h.normal[3 * k], h.normal[3 * k + 1], h.normal[3 * k + 2]);
+  t.tag = h.color_tag[k];
+  for (int q = 0; q < 4; q++) t.rgba[q] = h.rgba[4 * k + q];
+  return t;
+}
+static __device__ __forceinline__ void store_tp(const PackedHits& h, uint64_t k, const FullTP& t) {
+  h.lat[k] = t.lat;
+  h.lon[k] = t.lon;
+  h.distance[k] = t.distance;
+  h.elevation[k] = t.elevation;
+  h.path_length[k] = t.path_length;
+  h.normal[3 * k] = t.normal.x;
+  h.normal[3 * k + 1] = t.normal.y;
+  h.normal[3 * k + 2] = t.normal.z;
+  h.color_tag[k] = t.tag;
+  for (int q = 0; q < 4; q++) h.rgba[4 * k + q] = t.rgba[q];
+}
+// TracePoint::interpolate (generators/mod.rs:33-43) + PixelColor::interpolate (:67-79)
+static __device__ FullTP tp_interpolate(const FullTP& a, const FullTP& b, double c) {
+  FullTP r;
+  r.lat = a.lat * (1.0 - c) + b.lat * c;
+  r.lon = a.lon * (1.0 - c) + b.lon * c;
+  r.distance = a.distance * (1.0 - c) + b.distance * c;
+  r.elevation = a.elevation * (1.0 - c) + b.elevation * c;
+  r.path_length = a.path_length * (1.0 - c) + b.path_length * c;
+  r.normal = v3(a.normal.x * (1.0 - c) + b.normal.x * c, a.normal.y * (1.0 - c) + b.normal.y * c,
+                a.normal.z * (1.0 - c) + b.normal.z * c);
+  if (a.tag == ATMRT_COLOR_TERRAIN && b.tag == ATMRT_COLOR_TERRAIN) {
+    r.tag = ATMRT_COLOR_TERRAIN;
+    r.rgba[0] = r.rgba[1] = r.rgba[2] = 0.0;
+    r.rgba[3] = a.rgba[3] * (1.0 - c) + b.rgba[3] * c;
+  } else if (a.tag == ATMRT_COLOR_RGBA && b.tag == ATMRT_COLOR_RGBA) {
+    r.tag = ATMRT_COLOR_RGBA;
+    for (int q = 0; q < 4; q++) r.rgba[q] = a.rgba[q] * (1.0 - c) + b.rgba[q] * c;
+  } else {
+    r.tag = ATMRT_COLOR_TERRAIN;
+    r.rgba[0] = r.rgba[1] = r.rgba[2] = 0.0;
+    r.rgba[3] = a.tag == ATMRT_COLOR_TERRAIN ? a.rgba[3] : b.rgba[3];
+  }
+  return r;
+}
+
+constexpr int INTERP_MEMBERS = 64; // trace points of the four corner pixels together; more sets the error flag
+
+// interpolate_trace_points :267-337 on the group's corner members (index -1 = None)
+static __device__ bool interp_group(const LatticeResult& lr, const uint64_t* member_k, const int e[4], double re, double rd,
+                                    FullTP& out) {
+  int mask = (e[0] >= 0 ? 1 : 0) | (e[1] >= 0 ? 2 : 0) | (e[2] >= 0 ? 4 : 0) | (e[3] >= 0 ? 8 : 0);
+  auto tp = [&](int c) { return load_tp(lr.hits, member_k[e[c]]); };
+  auto two_adjacent = [&](int c0, int c1, double rem_elev, double rem_dir) { // :339-350
+    if (rem_elev >= 0.5) return false;
+    out = tp_interpolate(tp(c0), tp(c1), rem_dir);
+    return true;
+  };
+  auto two_diagonal = [&](int c0, int c1, double rem_elev, double rem_dir) { // :352-364
+    if ((rem_elev >= 0.5 && rem_dir < 0.5) || (rem_elev < 0.5 && rem_dir >= 0.5)) return false;
+    double coeff = rem_elev * rem_dir / (rem_elev * rem_dir + (1.0 - rem_elev) * (1.0 - rem_dir));
+    out = tp_interpolate(tp(c0), tp(c1), coeff);
+    return true;
+  };
+  auto three = [&](int c0, int c1, int c2, double rem_elev, double rem_dir) { // :366-380
+    if (rem_elev >= 0.5 && rem_dir >= 0.5) return false;
+    double sum = 1.0 - rem_elev + rem_elev * (1.0 - rem_dir);
+    FullTP in = tp_interpolate(tp(c0), tp(c1), rem_dir);
+    out = tp_interpolate(in, tp(c2), rem_elev * (1.0 - rem_dir) / sum);
+    return true;
+  };
+  switch (mask) {
+    case 0: return false;
+    case 1: if (re < 0.5 && rd < 0.5) { out = tp(0); return true; } return false;
+    case 2: if (re < 0.5 && rd >= 0.5) { out = tp(1); return true; } return false;
+    case 4: if (re >= 0.5 && rd < 0.5) { out = tp(2); return true; } return false;
+    case 8: if (re >= 0.5 && rd >= 0.5) { out = tp(3); return true; } return false;
+    case 1 | 2: return two_adjacent(0, 1, re, rd);
+    case 1 | 4: return two_adjacent(0, 2, rd, re);
+    case 1 | 8: return two_diagonal(0, 3, re, rd);
+    case 2 | 4: return two_diagonal(1, 2, re, 1.0 - rd);
+    case 2 | 8: return two_adjacent(1, 3, 1.0 - rd, re);
+    case 4 | 8: return two_adjacent(2, 3, 1.0 - re, rd);
+    case 1 | 2 | 4: return three(0, 1, 2, re, rd);
+    case 1 | 2 | 8: return three(1, 0, 3, re, 1.0 - rd);
+    case 1 | 4 | 8: return three(0, 3, 2, 1.0 - re, rd);
+    case 2 | 4 | 8: return three(3, 2, 1, 1.0 - re, 1.0 - rd);
+    default: {
+      FullTP i1 = tp_interpolate(tp(0), tp(1), rd);
+      FullTP i2 = tp_interpolate(tp(2), tp(3), rd);
+      out = tp_interpolate(i1, i2, re);
+      return true;
+    }
+  }
+}
+
+// interpolate :395-418 with collect_trace_points :213-243 and match_sequence :245-265
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_interp_blend(Frame f, InterpBuffers ib, LatticeResult lr, DensePlanes out,
+                                                      const uint64_t* __restrict__ hit_offset, PackedHits packed,
+                                                      unsigned long long* __restrict__ counters) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= f.wl) return;
+  const size_t p = (size_t)y * f.wl + x;
+  const double rem_elev = ib.rem_e[p], rem_dir = ib.rem_d[p];
+  const double step_size = f.p.simulation_step;
+  size_t corner[4]; // SEQUENCE = (0,0) (0,1) (1,0) (1,1): (elev_index + i, dir_index + j)
+  for (int s = 0; s < 4; s++)
+    corner[s] = (size_t)(ib.key_e[p] + (s >> 1) - f.ei0) * lr.nd + (size_t)(ib.key_d[p] + (s & 1) - f.di0);
+  uint64_t member_k[INTERP_MEMBERS];
+  double member_dist[INTERP_MEMBERS];
+  uint8_t member_corner[INTERP_MEMBERS], member_tag[INTERP_MEMBERS], member_group[INTERP_MEMBERS];
+  int n_members = 0, n_groups = 0;
+  for (int c = 0; c < 4; c++) {
+    if (!FILL) ib.referenced[corner[c]] = 1;
+    uint64_t k0 = lr.hit_offset[corner[c]];
+    uint32_t cnt = lr.hit_count[corner[c]];
+    for (uint32_t q = 0; q < cnt; q++) {
+      if (n_members >= INTERP_MEMBERS) {
+        atomicOr(&counters[2], 4ull);
+        break;
+      }
+      double dist = lr.hits.distance[k0 + q];
+      uint8_t tag = (uint8_t)lr.hits.color_tag[k0 + q];
+      int found = -1;
+      for (int g = 0; g < n_groups && found < 0; g++) // first group (creation order) with any close point of the same class
+        for (int m = 0; m < n_members; m++)
+          if (member_group[m] == g && dm_fabs(dist - member_dist[m]) < step_size && tag == member_tag[m]) {
+            found = g;
+            break;
+          }
+      if (found < 0) found = n_groups++;
+      member_k[n_members] = k0 + q;
+      member_dist[n_members] = dist;
+      member_corner[n_members] = (uint8_t)c;
+      member_tag[n_members] = tag;
+      member_group[n_members] = (uint8_t)found;
+      n_members++;
+    }
+  }
+  uint64_t k = FILL ? hit_offset[p] : 0;
+  unsigned count = 0;
+  for (int g = 0; g < n_groups; g++) {
+    int e[4] = {-1, -1, -1, -1};
+    for (int m = 0; m < n_members; m++)
+      if (member_group[m] == g) e[member_corner[m]] = m; // later entries overwrite, :247-263
+    FullTP tp;
+    if (interp_group(lr, member_k, e, rem_elev, rem_dir, tp)) {
+      if (FILL) store_tp(packed, k + count, tp);
+      count++;
+    }
+  }
+  if (!FILL) {
+    out.hit_count[p] = count;
+    double e0 = lr.elevation_angle[corner[0]], e1 = lr.elevation_angle[corner[1]], e2 = lr.elevation_angle[corner[2]],
+           e3 = lr.elevation_angle[corner[3]];
+    double a0 = lr.azimuth[corner[0]], a1 = lr.azimuth[corner[1]], a2 = lr.azimuth[corner[2]], a3 = lr.azimuth[corner[3]];
+    out.elevation_angle[p] = e0 * (1.0 - rem_elev) * (1.0 - rem_dir) + e1 * (1.0 - rem_elev) * rem_dir +
+                             e2 * rem_elev * (1.0 - rem_dir) + e3 * rem_elev * rem_dir;
+    out.azimuth[p] = a0 * (1.0 - rem_elev) * (1.0 - rem_dir) + a1 * (1.0 - rem_elev) * rem_dir + a2 * rem_elev * (1.0 - rem_dir) +
+                     a3 * rem_elev * rem_dir;
+  }
+}
+
+// ray-steps of the lattice pixels the image actually references (the reference memoises exactly those)
+__global__ __launch_bounds__(256) void k_lattice_steps(size_t n, const uint8_t* __restrict__ referenced,
+                                                       const uint32_t* __restrict__ px_steps,
+                                                       unsigned long long* __restrict__ counters) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = (i < n && referenced[i]) ? px_steps[i] : 0;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[0], v);
+}
+
+void launch_fov_table(const Frame& f, const InterpBuffers& ib, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fov_table, dim3(cdiv(f.p.width, 256), f.p.height), dim3(256), 0, stream, f, ib.dir, ib.elev);
+  hipLaunchKernelGGL(k_fov_colmin, dim3(cdiv(f.p.width, 256)), dim3(256), 0, stream, f, ib.elev, ib.colmin);
+  hipLaunchKernelGGL(k_fov_rowmin, dim3(cdiv(f.p.height, 64)), dim3(64), 0, stream, f, ib.dir, ib.rowmin);
+}
+void launch_lattice_keys(const Frame& f, const InterpBuffers& ib, double min_elev_step, double min_dir_step, hipStream_t stream) {
+  hipLaunchKernelGGL(k_lattice_keys, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ib, min_elev_step, min_dir_step);
+}
+void launch_interp_blend(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,
+                         const DensePlanes& dense, const PackedHits& packed, hipStream_t stream) {
+  dim3 grid(cdiv(f.wl, 256), f.h);
+  if (fill)
+    hipLaunchKernelGGL((k_interp_blend<true>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
+                       (unsigned long long*)ws.counters);
+  else
+    hipLaunchKernelGGL((k_interp_blend<false>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr, packed,
+                       (unsigned long long*)ws.counters);
+}
+void launch_interp_finish(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr,
+                          const DensePlanes& dense, const PackedHits& packed, hipStream_t stream) {
+  size_t n = (size_t)lr.nd * lr.ne;
+  hipLaunchKernelGGL(k_lattice_steps, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, ib.referenced, lr.px_steps,
+                     (unsigned long long*)ws.counters);
+  hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed, dense, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // harness kernels
 // ---------------------------------------------------------------------------------------------
@@ -961,7 +1263,6 @@ __global__ void k_coords_at_dist(Frame f, double lat0, double lon0, double dir, 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 void launch_resolve(const Frame& f, Workspace& ws, ObjectDev* objects_mut, hipStream_t stream) {
   hipLaunchKernelGGL(k_resolve, dim3(cdiv((size_t)f.n_objects + 1, 64)), dim3(64), 0, stream, f, ws.alt, objects_mut);
@@ -997,10 +1298,10 @@ void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out
   dim3 grid(cdiv(f.wl, 64), cdiv(f.h, 4 * FAST_RR));
   if (f.opaque)
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 0>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                       ws.hit_step, out.hit_count, (unsigned long long*)ws.counters);
+                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters);
   else
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 1>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                       ws.hit_step, out.hit_count, (unsigned long long*)ws.counters);
+                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters);
 }
 
 void launch_fast_finalize(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
@@ -1074,7 +1375,7 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
   } else {
     hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                        ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, out.hit_count, (const uint64_t*)nullptr,
-                       none, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
+                       none, (uint32_t*)nullptr, (uint32_t*)nullptr, ws.px_steps, (unsigned long long*)ws.counters);
   }
 }
 
@@ -1095,7 +1396,7 @@ void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
   } else {
     hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                        ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, dense.hit_count, ws.hit_offset, packed,
-                       ws.list_step, ws.list_pixel, (unsigned long long*)ws.counters);
+                       ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
     if (n_hits) {
       ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                             stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,

@@ -48,7 +48,7 @@ def test_oracle_reproduces_golden(path, flavour, oracle_det, oracle_libm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", [p for p in GOLDEN if "interp" not in p], ids=[os.path.basename(p)[:-4] for p in GOLDEN if "interp" not in p])
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_gpu_reproduces_golden(path, gpu_ctx):
     cfg, tiles, z, meta = load(path)
     check(run_gpu(gpu_ctx, cfg, tiles), z, meta, 1e-9)

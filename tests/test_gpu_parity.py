@@ -158,3 +158,21 @@ def test_scene_objects(gpu_ctx, oracle_det, generator, w, h, alpha):
 def test_scene_objects_flat_earth(gpu_ctx, oracle_det):
     cfg, tiles = _object_scene("Fast", 64, 32, 0.5, earth_shape="FlatDistorted")
     assert_bitexact(run_gpu(gpu_ctx, cfg, tiles), run_oracle(oracle_det, cfg, tiles))
+
+
+@pytest.mark.parametrize("kw", [{}, {"terrain_alpha": 0.5, "tilt": -4.0}, {"earth_shape": "Wgs84"}, {"fov": 100.0, "tilt": -8.0}],
+                         ids=["opaque", "translucent", "wgs84", "wide-fov"])
+def test_interpolating_rectilinear(gpu_ctx, oracle_det, kw):
+    """InterpolatingRectilinear (interpolating_rectilinear.rs): lattice of Fast-style pixels + the 15-case 4-corner blend."""
+    cfg, tiles = synth.scene("S2", 72, 40, generator="InterpolatingRectilinear", max_distance=80_000.0, **kw)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert got["n_hits"] > 0
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
+def test_interpolating_rectilinear_with_objects_and_shard(gpu_ctx, oracle_det):
+    cfg, tiles = _object_scene("InterpolatingRectilinear", 64, 32, 0.5)
+    cfg.params.col_begin, cfg.params.col_end = 16, 56
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert (got["color_tag"] == 1).sum() > 10
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))

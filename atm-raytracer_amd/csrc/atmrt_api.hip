@@ -85,7 +85,7 @@ struct atmrt_ctx {
   // workspace
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
-      d_ccount, d_coffset, d_clist, d_px_steps, d_interp, d_lat_dense, d_lat_packed, d_lat_offset;
+      d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -256,7 +256,7 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
   for (DevBuf* b : {&c->d_posts, &c->d_tiles, &c->d_cells, &c->d_xs, &c->d_alt, &c->d_colcalc, &c->d_prof, &c->d_pelev,
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
-                    &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
+                    &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
                     &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io})
     b->release();
   for (hipEvent_t ev : c->ev)
@@ -526,7 +526,9 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   Frame f{};
   f.p = p;
   f.earth = c->earth;
-  f.atm = c->atm;
+  HIP_TRY(c, c->d_atm.reserve(sizeof(AtmTable)));
+  HIP_TRY(c, hipMemcpy(c->d_atm.ptr, &c->atm, sizeof(AtmTable), hipMemcpyHostToDevice));
+  f.atm = c->d_atm.as<AtmTable>();
   f.ph = c->pinhole;
   f.tv = c->tv;
   HIP_TRY(c, c->d_alt.reserve(sizeof(double)));

@@ -125,21 +125,50 @@ ATMRT_HD double atm_pressure(const AtmTable& a, double h) {
   return a.pb[k] * atm_pressure_ratio(a, k, h);
 }
 
-// Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).
-ATMRT_HD double refr_n(const AtmTable& a, double h) {
+// Environment::n(h) for a point known to lie in the layer with these parameters
+ATMRT_HD double refr_n_layer(double k_refr, double hb, double tb, double pb, double lapse, double expo, double h) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
-  int k = atm_layer(a, h);
-  double temp = a.tb[k] + a.lapse[k] * (h - a.hb[k]);
-  double p = a.pb[k] * atm_pressure_ratio(a, k, h);
+  double temp = tb + lapse * (h - hb);
+  double ratio = lapse != 0.0 ? dm_pow(temp / tb, expo) : dm_exp(expo * (h - hb));
+  double p = pb * ratio;
   double t = temp - 273.15;
   double pt = p / temp;
   double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
-  return 1.0 + a.k_refr * pt / z;
+  return 1.0 + k_refr * pt / z;
+}
+
+// Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).
+ATMRT_HD double refr_n(const AtmTable& a, double h) {
+  int k = atm_layer(a, h);
+  return refr_n_layer(a.k_refr, a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.expo[k], h);
 }
 ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   const double eps = 0.01;
   double n1 = refr_n(a, h - eps);
   double n2 = refr_n(a, h + eps);
+  return (n2 - n1) / (2.0 * eps);
+}
+
+// Same values as refr_n, organised for the wavefront: `hint` is the layer of the previous evaluation.  When every
+// active lane is still inside that layer (the normal case: rays stay below 11 km) the layer search is two compares and
+// the layer parameters are wave-uniform scalars; otherwise the lane falls back to the full search and a gather.
+ATMRT_HD double refr_n_hint(const AtmTable& a, double h, int& hint) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ku = __builtin_amdgcn_readfirstlane(hint);
+  const bool ok = (ku == 0 || h >= a.from[ku]) && (ku == a.n - 1 || h < a.from[ku + 1]);
+  if (__all(ok)) return refr_n_layer(a.k_refr, a.hb[ku], a.tb[ku], a.pb[ku], a.lapse[ku], a.expo[ku], h);
+  const int k = ok ? ku : atm_layer(a, h);
+  hint = k;
+  return refr_n_layer(a.k_refr, a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.expo[k], h);
+#else
+  (void)hint;
+  return refr_n(a, h);
+#endif
+}
+ATMRT_HD double refr_dn_hint(const AtmTable& a, double h, int& hint) {
+  const double eps = 0.01;
+  double n1 = refr_n_hint(a, h - eps, hint);
+  double n2 = refr_n_hint(a, h + eps, hint);
   return (n2 - n1) / (2.0 * eps);
 }
 
@@ -454,12 +483,14 @@ struct RayState { // RayState {x, h, dh}
 struct Stepper {
   double x, a, b;  // flat: a = h, b = dh/dx; spherical: a = r, b = dr/dphi
   double h0, ang;  // straight rays: closed form from the start point
+  int hint;        // atmosphere layer of the last n(h) evaluation (speed only, never changes a result)
 };
 
 ATMRT_HD void stepper_init(Stepper& s, bool spherical, double radius, double h0, double ang_rad) {
   s.x = 0.0;
   s.h0 = h0;
   s.ang = ang_rad;
+  s.hint = 0;
   if (spherical) {
     s.a = h0 + radius;
     s.b = s.a * dm_tan(ang_rad);
@@ -469,21 +500,22 @@ ATMRT_HD void stepper_init(Stepper& s, bool spherical, double radius, double h0,
   }
 }
 
-ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b) {
+ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b, int& hint) {
   if (spherical) {
     double h = a - radius;
-    double n = refr_n(atm, h);
-    double dn = refr_dn(atm, h);
+    double n = refr_n_hint(atm, h, hint);
+    double dn = refr_dn_hint(atm, h, hint);
     return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
   }
-  double n = refr_n(atm, a);
-  double dn = refr_dn(atm, a);
+  double n = refr_n_hint(atm, a, hint);
+  double dn = refr_dn_hint(atm, a, hint);
   return (1.0 + b * b) * dn / n;
 }
 
-// PathStepper::next: the state after one more step of `step` metres in x
-ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight,
-                               double step) {
+// PathStepper::next: the state after one more step of `step` metres in x.  `accel(spherical, radius, a, b, hint)` is
+// the right-hand side of the ODE; the GPU path kernel substitutes a version that spreads its n(h) evaluations over lanes.
+template <class Accel>
+ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, bool straight, double step, const Accel& accel) {
   RayState out;
   if (straight) {
     s.x = s.x + step;
@@ -504,13 +536,13 @@ ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, 
   double half = 0.5 * d, sixth = d / 6.0;
   double a = s.a, b = s.b;
   double k1a = b;
-  double k1b = ray_accel(atm, spherical, radius, a, b);
+  double k1b = accel(spherical, radius, a, b, s.hint);
   double k2a = b + half * k1b;
-  double k2b = ray_accel(atm, spherical, radius, a + half * k1a, k2a);
+  double k2b = accel(spherical, radius, a + half * k1a, k2a, s.hint);
   double k3a = b + half * k2b;
-  double k3b = ray_accel(atm, spherical, radius, a + half * k2a, k3a);
+  double k3b = accel(spherical, radius, a + half * k2a, k3a, s.hint);
   double k4a = b + d * k3b;
-  double k4b = ray_accel(atm, spherical, radius, a + d * k3a, k4a);
+  double k4b = accel(spherical, radius, a + d * k3a, k4a, s.hint);
   s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
   s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
   s.x = s.x + step;
@@ -523,6 +555,17 @@ ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, 
     out.dh = s.b;
   }
   return out;
+}
+
+struct SerialAccel {
+  const AtmTable& atm;
+  ATMRT_HD double operator()(bool spherical, double radius, double a, double b, int& hint) const {
+    return ray_accel(atm, spherical, radius, a, b, hint);
+  }
+};
+ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight,
+                               double step) {
+  return stepper_next_with(s, spherical, radius, straight, step, SerialAccel{atm});
 }
 
 // calc_dist, utils.rs:42-53

@@ -11,7 +11,7 @@ namespace atmrt {
 struct Frame {
   atmrt_params_t p;
   Earth earth;
-  AtmTable atm;
+  const AtmTable* atm;      // layer table in global memory: wave-uniform indices become scalar loads
   Pinhole ph;
   TerrainView tv;
   const double* alt;        // device scalar: observer altitude after Altitude::abs (params.rs:23-30)

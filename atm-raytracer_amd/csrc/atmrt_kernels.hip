@@ -165,35 +165,72 @@ __global__ __launch_bounds__(256) void k_terrain_profile(Frame f, const DirCalc*
   }
 }
 
-// Phase B.  One lane integrates one row's ray; rows are independent and the chain is sequential.
+// Phase B.  Rows are independent and each ray is a sequential RK4 chain (H-way parallelism only), so the kernel is
+// latency-bound.  Each ray is given a QUAD of lanes: the three independent n(h) evaluations of an RK4 stage
+// (n(h), n(h - eps), n(h + eps) of Environment::n / dn) run on lanes 0..2 of the quad and are exchanged with
+// shuffles; the cheap remainder of the stage is computed redundantly by all four lanes.  Same operations, same order
+// per value, a third of the dependent chain.
+struct QuadAccel {
+  const AtmTable& atm;
+  int sub, base;
+  __device__ __forceinline__ double operator()(bool spherical, double radius, double a, double b, int& hint) const {
+    const double eps = 0.01;
+    double h = spherical ? a - radius : a;
+    double hh = sub == 1 ? h - eps : sub == 2 ? h + eps : h;
+    double nv = refr_n_hint(atm, hh, hint);
+    double n = __shfl(nv, base, 64), n1 = __shfl(nv, base + 1, 64), n2 = __shfl(nv, base + 2, 64);
+    double dn = (n2 - n1) / (2.0 * eps);
+    if (spherical) return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
+    return (1.0 + b * b) * dn / n;
+  }
+};
+
 __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__ pelev, double* __restrict__ plen,
                                                    int32_t* __restrict__ npath) {
-  int y = blockIdx.x * blockDim.x + threadIdx.x;
-  if (y >= f.h) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub = t & 3;
+  const int y = (t >> 2) < f.h ? (t >> 2) : f.h - 1; // surplus quads repeat the last row (every lane must reach the shuffles)
+  const bool writer = sub == 0 && (t >> 2) < f.h;
   const bool sph = f.earth.spherical != 0;
   const double radius = f.earth.shape_radius;
   const bool straight = f.p.straight_rays != 0;
   const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
   const double alt = *f.alt;
+  const QuadAccel accel{*f.atm, sub, (int)(threadIdx.x & 63 & ~3)};
   Stepper s;
   stepper_init(s, sph, radius, alt, dm_to_radians(frame_row_elev(f, y)));
   size_t base = (size_t)y * f.n_path_cap;
-  pelev[base] = alt;
-  plen[base] = 0.0;
+  if (writer) {
+    pelev[base] = alt;
+    plen[base] = 0.0;
+  }
   int n = 1;
   double px = 0.0, ph = alt, path_length = 0.0;
-  // utils.rs:159-171: push, then stop once the PREVIOUS state is beyond max_distance or below -1000 m
-  while (n < f.n_path_cap) {
-    RayState st = stepper_next(s, f.atm, sph, radius, straight, step);
+  // utils.rs:159-171: push, then stop once the PREVIOUS state is beyond max_distance or below -1000 m.
+  // The loop bound is wave-uniform; a quad that has finished keeps stepping without storing, so that every lane of
+  // the wavefront takes part in every shuffle.
+  bool done = false;
+  int n_final = 0;
+  for (int i = 1; i < f.n_path_cap; i++) {
+    RayState st = stepper_next_with(s, sph, radius, straight, step, accel);
     path_length += calc_dist(sph, radius, px, ph, st.x, st.h);
-    pelev[base + n] = st.h;
-    plen[base + n] = path_length;
-    n++;
-    if (px > max_dist || ph < -1000.0) break;
+    if (!done) {
+      if (writer) {
+        pelev[base + n] = st.h;
+        plen[base + n] = path_length;
+      }
+      n++;
+      if (px > max_dist || ph < -1000.0) {
+        done = true;
+        n_final = n;
+      }
+    }
     px = st.x;
     ph = st.h;
+    if (__all(done)) break;
   }
-  npath[y] = n;
+  if (!done) n_final = n;
+  if (writer) npath[y] = n_final;
 }
 
 // Phase C.  Lanes = 64 adjacent columns, each wavefront owns RR adjacent rows.  The terrain value
@@ -415,8 +452,12 @@ struct RectRec {
   double* pl1;
 };
 
+// 4 waves per SIMD (<= 128 VGPRs): measured 790 ms (3 waves) -> 702 ms (4) on the headline frame; 5 and 6 spill
+#ifndef ATMRT_MARCH_WAVES
+#define ATMRT_MARCH_WAVES 4
+#endif
 template <int MODE, int CALC>
-__global__ __launch_bounds__(256) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+__global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters) {
@@ -450,7 +491,7 @@ __global__ __launch_bounds__(256) void k_rect_march(Frame f, DensePlanes out, in
       double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh = alt, path_length = 0.0;
       for (int i = 1;; i++) {
-        RayState st = stepper_next(s, f.atm, sph, radius, straight, step);
+        RayState st = stepper_next(s, *f.atm, sph, radius, straight, step);
         path_length += calc_dist(sph, radius, sx, sh, st.x, st.h);
         sx = st.x;
         sh = st.h;
@@ -766,7 +807,7 @@ __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, co
       double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh_ = alt, path_length = 0.0;
       for (int i = 1;; i++) {
-        RayState st = stepper_next(s, f.atm, sph, radius, straight, step);
+        RayState st = stepper_next(s, *f.atm, sph, radius, straight, step);
         path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h);
         sx = st.x;
         sh_ = st.h;
@@ -1238,7 +1279,7 @@ __global__ void k_ray_paths(Frame f, double h0, size_t n_angles, const double* a
   x[base] = 0.0;
   h[base] = h0;
   for (size_t k = 1; k <= n_steps; k++) {
-    RayState st = stepper_next(s, f.atm, sph, f.earth.shape_radius, straight != 0, step);
+    RayState st = stepper_next(s, *f.atm, sph, f.earth.shape_radius, straight != 0, step);
     x[base + k] = st.x;
     h[base + k] = st.h;
   }
@@ -1246,10 +1287,10 @@ __global__ void k_ray_paths(Frame f, double h0, size_t n_angles, const double* a
 __global__ void k_atm_sample(Frame f, size_t n, const double* alt, double* t, double* p, double* nidx, double* dn) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  t[i] = atm_temperature(f.atm, alt[i]);
-  p[i] = atm_pressure(f.atm, alt[i]);
-  nidx[i] = refr_n(f.atm, alt[i]);
-  dn[i] = refr_dn(f.atm, alt[i]);
+  t[i] = atm_temperature(*f.atm, alt[i]);
+  p[i] = atm_pressure(*f.atm, alt[i]);
+  nidx[i] = refr_n(*f.atm, alt[i]);
+  dn[i] = refr_dn(*f.atm, alt[i]);
 }
 __global__ void k_coords_at_dist(Frame f, double lat0, double lon0, double dir, size_t n, const double* dist, double* lat,
                                  double* lon) {
@@ -1276,7 +1317,7 @@ void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipSt
   (void)hipEventRecord(ev, stream);
   (void)hipStreamWaitEvent(stream2, ev, 0);
   (void)hipEventRecord(timing[2], stream2);
-  hipLaunchKernelGGL(k_fast_paths, dim3(cdiv(f.h, 64)), dim3(64), 0, stream2, f, ws.pelev, ws.plen, ws.npath);
+  hipLaunchKernelGGL(k_fast_paths, dim3(cdiv((size_t)f.h * 4, 64)), dim3(64), 0, stream2, f, ws.pelev, ws.plen, ws.npath);
   (void)hipEventRecord(timing[3], stream2);
   (void)hipEventRecord(ev_join, stream2);
   (void)hipEventRecord(timing[0], stream);

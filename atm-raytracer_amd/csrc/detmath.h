@@ -72,7 +72,9 @@ DM_FN int dm_rem_pio2(double x, double* y0, double* y1) {
   double a = r1 + tail;
   *y0 = a;
   *y1 = (r1 - a) + tail;
-  return (int)((int64_t)fn & 3);
+  /* |fn| < 2^31 for every reduced argument that is meaningful; saturate the rest (results are NaN or inaccurate anyway) */
+  if (!(fn > -2147483000.0 && fn < 2147483000.0)) fn = 0.0;
+  return (int)fn & 3;
 }
 
 DM_FN double dm_ksin(double x, double y) {
@@ -97,29 +99,17 @@ DM_FN double dm_kcos(double x, double y) {
   return t + (((1.0 - t) - hz) + (z * r - x * y));
 }
 
+/* Straight-line: the reduction is exact for |x| <= pi/4 as well (n = 0, y0 = x, y1 = 0), so there is no
+ * small-argument branch, and the quadrant is applied with selects.  inf/nan propagate as NaN. */
 DM_FN void dm_sincos(double x, double* s, double* c) {
-  double y0, y1;
-  int n;
-  double ks, kc;
-  if (dm_fabs(x) <= 0.7853981633974483) {
-    *s = dm_ksin(x, 0.0);
-    *c = dm_kcos(x, 0.0);
-    return;
-  }
-  if (dm_isnan(x) || dm_isinf(x)) {
-    *s = x - x;
-    *c = x - x;
-    return;
-  }
-  n = dm_rem_pio2(x, &y0, &y1);
+  double y0, y1, ks, kc, ss, cc;
+  int n = dm_rem_pio2(x, &y0, &y1);
   ks = dm_ksin(y0, y1);
   kc = dm_kcos(y0, y1);
-  switch (n) {
-    case 0: *s = ks; *c = kc; break;
-    case 1: *s = kc; *c = -ks; break;
-    case 2: *s = -ks; *c = -kc; break;
-    default: *s = -kc; *c = ks; break;
-  }
+  ss = (n & 1) ? kc : ks;
+  cc = (n & 1) ? ks : kc;
+  *s = (n & 2) ? -ss : ss;
+  *c = ((n + 1) & 2) ? -cc : cc;
 }
 DM_FN double dm_sin(double x) {
   double s, c;
@@ -261,7 +251,7 @@ DM_FN double dm_asin(double x) {
 
 /* ---- exp / log / pow ------------------------------------------------------------------- */
 
-DM_FN double dm_exp(double x) {
+DM_FN double dm_exp_slow(double x) { /* |x| < 2^-28, |x| > 700, nan */
   const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00;
   const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
@@ -273,43 +263,49 @@ DM_FN double dm_exp(double x) {
   if (x > 709.782712893384) return dm_inf();
   if (x < -745.1332191019411) return 0.0;
   if (dm_fabs(x) < 3.725290298461914e-09) return 1.0 + x; /* 2^-28 */
-  if (dm_fabs(x) > 0.34657359027997264) {                  /* 0.5 ln2 */
-    fk = dm_rint(x * invln2);
-    hi = x - fk * ln2hi;
-    lo = fk * ln2lo;
-    r = hi - lo;
-    k = (int64_t)fk;
-  } else {
-    hi = x; lo = 0.0; r = x; k = 0;
-  }
+  fk = dm_rint(x * invln2);
+  hi = x - fk * ln2hi;
+  lo = fk * ln2lo;
+  r = hi - lo;
+  k = (int64_t)fk;
   t = r * r;
   c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
   y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-  if (k == 0) return y;
   if (k >= -1021 && k <= 1023) return y * dm_from_bits((uint64_t)(k + 1023) << 52);
   if (k > 1023) return (y * dm_from_bits((uint64_t)(k - 1 + 1023) << 52)) * 2.0;
   /* gradual underflow: scale in two exact-power steps */
   return (y * dm_from_bits((uint64_t)(k + 1000 + 1023) << 52)) * dm_from_bits((uint64_t)(1023 - 1000) << 52);
 }
 
-DM_FN double dm_log(double x) {
+/* exp(x) = 2^k exp(r), r = x - k ln2 in [-ln2/2, ln2/2]; exp(r) = 1 + r + r c/(2 - c) (K.C. Ng's form).
+ * The main range 2^-28 <= |x| <= 700 is one straight line (for |x| <= ln2/2 the reduction gives k = 0 and
+ * r = x exactly, so no small-argument branch is needed); everything else goes to dm_exp_slow. */
+DM_FN double dm_exp(double x) {
+  const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+               P5 = 4.13813679705723846039e-08;
+  double ax = dm_fabs(x), fk, hi, lo, r, t, c, y;
+  if (!(ax >= 3.725290298461914e-09 && ax <= 700.0)) return dm_exp_slow(x);
+  fk = dm_rint(x * invln2);
+  hi = x - fk * ln2hi;
+  lo = fk * ln2lo;
+  r = hi - lo;
+  t = r * r;
+  c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return y * dm_from_bits((uint64_t)((int64_t)fk + 1023) << 52); /* |k| <= 1010 here */
+}
+
+DM_FN double dm_log_core(double x, int64_t k) { /* x positive and normal */
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                Lg7 = 1.479819860511658591e-01;
-  uint64_t ix;
-  int64_t k = 0;
+  uint64_t ix = dm_bits(x);
   double f, s, z, w, t1, t2, R, hfsq, dk;
-  if (dm_isnan(x)) return x + x;
-  if (x < 0.0) return (x - x) / (x - x);
-  if (x == 0.0) return -dm_inf();
-  if (dm_isinf(x)) return x;
-  if (x < 2.2250738585072014e-308) { /* subnormal: scale by 2^54 */
-    x *= 18014398509481984.0;
-    k = -54;
-  }
-  ix = dm_bits(x);
   /* normalise to [sqrt(2)/2, sqrt(2)) */
   ix += 0x3ff0000000000000ULL - 0x3fe6a09e00000000ULL;
   k += (int64_t)(ix >> 52) - 1023;
@@ -325,6 +321,17 @@ DM_FN double dm_log(double x) {
   R = t2 + t1;
   dk = (double)k;
   return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+DM_FN double dm_log_slow(double x) { /* nan, negative, zero, inf, subnormal */
+  if (dm_isnan(x)) return x + x;
+  if (x < 0.0) return (x - x) / (x - x);
+  if (x == 0.0) return -dm_inf();
+  if (dm_isinf(x)) return x;
+  return dm_log_core(x * 18014398509481984.0, -54); /* subnormal: scale by 2^54 */
+}
+DM_FN double dm_log(double x) {
+  if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return dm_log_slow(x);
+  return dm_log_core(x, 0);
 }
 
 /* x > 0 only (barometric formula: base = T/T_b in (0, 2)).  <= 3 ulp for |y ln x| <= 4. */

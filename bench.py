@@ -32,12 +32,12 @@ def log(*a):
 
 def cpu_baseline(generator, seconds_budget=30.0):
     """The oracle (CPU restatement of the reference, glibc-libm flavour, OpenMP over all host cores) on a
-    bounded sample of the same scene: the headline frame at 1/4 (Fast) or 1/64 (Rectilinear) of the pixels
+    bounded sample of the same scene: the headline frame at 1/2 (Fast) or 1/16 (Rectilinear) of the pixels
     with identical step / max_distance / field of view (about 10-30 s of CPU work on 16 threads)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
     from atm_raytracer_amd import synth
-    w, h = (2048, 1024) if generator == "Fast" else (512, 256)
+    w, h = (4096, 1024) if generator == "Fast" else (1024, 512)
     cfg, tiles = synth.scene("headline", w, h, generator=generator, level=1)
     oracle = Oracle("libm")
     t = oracle.terrain_new(tiles)
@@ -150,15 +150,24 @@ def main():
         return elapsed, marched, phase
 
     def roofline(generator_name, phase):
-        """Dominant kernel of the generator: algorithmic bytes (8 B per ray-step + 88 B per pixel
-        + 64 B per hit) over its mean launch duration from the library's HIP events."""
-        key = "march_ms" if generator_name == "Rectilinear" else max(("intersect_ms", "paths_ms", "profile_ms"), key=lambda k: np.mean([p[k] for p in phase]))
-        ms = float(np.mean([p[key] for p in phase]))
-        steps_per_launch = float(np.mean([p["ray_steps"] for p in phase]))
-        hits = int((local["hit_count"] > 0).sum().item())
-        algo_bytes = 8.0 * steps_per_launch + 88.0 * wl * H + 64.0 * hits
+        """Dominant (longest) kernel of the generator: ITS algorithmic bytes over its mean launch duration from the
+        library's HIP events.  Per-unit figures: the march and the Fast intersect scan are credited
+        8 B per ray-step (the 4 int16 posts of one bilinear lookup, SURVEY.md §8d) plus what they store per pixel;
+        the Fast path kernel stores 16 B per step of every row; the terrain profile reads 8 B and stores 8 B per sample."""
+        mean = lambda k: float(np.mean([p[k] for p in phase]))
+        steps_per_launch = mean("ray_steps")
+        n_path, n_t = 2003.0, 2000.0  # samples per ray at 100 m / 200 km (xs table; utils.rs:160-170, 191-196)
+        per_kernel = {
+            "march_ms": ("k_rect_march", 8.0 * steps_per_launch + (8 + 8 + 4 + 4) * wl * H),
+            "intersect_ms": ("k_fast_intersect", 8.0 * steps_per_launch + 8.0 * wl * H),
+            "paths_ms": ("k_fast_paths", 16.0 * n_path * H),
+            "profile_ms": ("k_terrain_profile", 16.0 * n_t * wl),
+        }
+        keys = ["march_ms"] if generator_name == "Rectilinear" else ["intersect_ms", "paths_ms", "profile_ms"]
+        key = max(keys, key=mean)
+        kernel, algo_bytes = per_kernel[key]
+        ms = mean(key)
         achieved = algo_bytes / (ms * 1e-3) / 1e9
-        kernel = {"march_ms": "k_rect_march", "intersect_ms": "k_fast_intersect", "paths_ms": "k_fast_paths", "profile_ms": "k_terrain_profile"}[key]
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
         if os.path.exists(pmc_file) and world == 1 and (W, H) == (4096, 2048):
@@ -166,16 +175,19 @@ def main():
             # command (counters cannot be read from inside the process); FETCH_SIZE doubled per the gfx950 note
             pmc = json.load(open(pmc_file))
             for name, v in pmc.items():
-                if kernel in name and "finalize" not in name:
+                if kernel in name:
                     traffic, traffic_src = v["hbm_bytes_per_launch_fetch_x2"], "profiles/pmc_hbm_latest.json"
         out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
-               "phase_ms": {k: float(np.mean([p[k] for p in phase])) for k in phase[0] if k.endswith("_ms")}}
+               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": ms,
+               "algorithmic_bytes_per_launch": algo_bytes,
+               "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
+               "all_kernels": {per_kernel[k][0]: {"ms": mean(k), "algorithmic_GBps": per_kernel[k][1] / (mean(k) * 1e-3) / 1e9}
+                               for k in keys if mean(k) > 0}}
         if generator_name == "Rectilinear":
-            # secondary, honest figure: the march is FP64-VALU bound, ~0.9 kFLOP per ray-step
-            tf = 900.0 * steps_per_launch / (ms * 1e-3) / 1e12
-            out["fp64_valu"] = {"achieved_tflops_est": tf, "peak_tflops": FP64_VALU_PEAK_TF, "frac_est": tf / FP64_VALU_PEAK_TF,
-                                "flop_per_ray_step_est": 900}
+            # secondary, honest figure: the march is FP64-VALU bound.  rocprofv3 SQ counters (profiles/r01/sq_counters_march.json):
+            # ~2,470 VALU instructions per ray-step, most of them FP64 at 16 lanes/clk/SIMD
+            out["fp64_valu"] = {"valu_instructions_per_ray_step": 2470, "valu_busy_frac_measured_r01": 0.73,
+                                "note": "not HBM-bound: 78 fp64 divisions + 12 pow per RK4 step; see DESIGN.md §4"}
         return out
 
     elapsed, marched, phase = timed(args.generator, args.steps, args.warmup)

@@ -31,6 +31,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 and cannot
+    # initialise after the system copy has claimed the device ("No HIP GPUs are available").  Importing torch first
+    # makes libatmrt.so bind to the runtime torch uses, so both share devices, streams and allocations.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950); "
                           "this package has no CPU fallback")

@@ -233,9 +233,10 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   if (writer) npath[y] = n_final;
 }
 
-// Phase C.  Lanes = 64 adjacent columns, each wavefront owns RR adjacent rows.  The terrain value
-// prof[i][x] is loaded once per lane (coalesced) and reused for RR rows; the ray elevation
-// pelev[y][i] is wave-uniform (scalar loads).  MODE 0: opaque terrain, stop at the first hit.
+// Phase C.  Lanes = 64 adjacent columns, each wavefront owns RR adjacent rows.  The terrain value prof[i][x] is
+// loaded once per lane (coalesced) and reused for RR rows; the ray elevations pelev[y][i..i+CH) are wave-uniform and
+// arrive as wide scalar loads.  The body is branch-free (selects), samples are processed CH at a time and the
+// all-lanes-finished test (MODE 0) runs once per chunk.  MODE 0: opaque terrain, first sign change only.
 // MODE 1: count every sign change (terrain_alpha < 1).
 template <int RR, int MODE>
 __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* __restrict__ prof,
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
                                                         uint32_t* __restrict__ hit_count,
                                                         uint32_t* __restrict__ px_steps,
                                                         unsigned long long* __restrict__ counters) {
+  constexpr int CH = 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x = blockIdx.x * 64 + lane;
@@ -252,56 +254,74 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
   const int xc = xok ? x : f.wl - 1;
   const int y0 = (blockIdx.y * 4 + wave) * RR;
   const int cap = f.n_path_cap;
+  const size_t wl = (size_t)f.wl;
   if (y0 >= f.h) return;
 
+  // rows past the image repeat the last row (identical work, never stored), so the fast loop stays uniform
+  const double* prow[RR];
   int nrow[RR];
   double dprev[RR];
   int first[RR];
   unsigned cnt[RR];
-  int nmax = 0;
+  int nmin = 0x7fffffff, nmax = 0;
   const double t0 = prof[xc];
 #pragma unroll
   for (int r = 0; r < RR; r++) {
-    int y = y0 + r;
-    int n = 0;
-    if (y < f.h) {
-      n = npath[y];
-      n = n < f.n_t ? n : f.n_t; // Iterator::zip, fast.rs:59-62
-    }
+    int y = y0 + r < f.h ? y0 + r : f.h - 1;
+    int n = npath[y];
+    n = n < f.n_t ? n : f.n_t; // Iterator::zip, fast.rs:59-62
     nrow[r] = n;
+    nmin = n < nmin ? n : nmin;
     nmax = n > nmax ? n : nmax;
+    prow[r] = pelev + (size_t)y * cap;
     first[r] = -1;
     cnt[r] = 0;
-    dprev[r] = (y < f.h) ? pelev[(size_t)y * cap] - t0 : 0.0;
+    dprev[r] = prow[r][0] - t0;
   }
-  int open = 0; // rows of this lane still marching (MODE 0)
+  int nfound = 0; // rows of this lane that have their first hit (MODE 0)
+  bool alldone = false;
+  int i = 1;
+  for (; i + CH <= nmin; i += CH) {
+    double t[CH];
 #pragma unroll
-  for (int r = 0; r < RR; r++) open += nrow[r] > 1;
-
-  for (int i = 1; i < nmax; i++) {
-    const double t = prof[(size_t)i * f.wl + xc];
+    for (int k = 0; k < CH; k++) t[k] = prof[(size_t)(i + k) * wl + xc];
 #pragma unroll
     for (int r = 0; r < RR; r++) {
-      if (i < nrow[r]) {
-        const double d = pelev[(size_t)(y0 + r) * cap + i] - t;
+      const double* pr = prow[r] + i;
+      double p[CH];
+#pragma unroll
+      for (int k = 0; k < CH; k++) p[k] = pr[k];
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const double d = p[k] - t[k];
         const bool hit = dprev[r] * d < 0.0; // utils.rs:222
-        if (MODE == 0) {
-          if (hit && first[r] < 0) {
-            first[r] = i - 1;
-            open--;
-          } else if (i == nrow[r] - 1 && first[r] < 0) {
-            open--;
-          }
-        } else {
-          if (hit) {
-            if (first[r] < 0) first[r] = i - 1;
-            cnt[r]++;
-          }
-        }
+        const bool nh = hit && first[r] < 0;
+        first[r] = nh ? i + k - 1 : first[r];
+        if (MODE == 0) nfound += nh ? 1 : 0;
+        else cnt[r] += hit ? 1u : 0u;
         dprev[r] = d;
       }
     }
-    if (MODE == 0 && __all(open <= 0)) break;
+    if (MODE == 0 && __all(nfound == RR)) {
+      alldone = true;
+      break;
+    }
+  }
+  if (!alldone) { // remainder of the chunking and rows whose path ended early (ray below -1000 m, utils.rs:167)
+    for (; i < nmax; i++) {
+      const double t = prof[(size_t)i * wl + xc];
+#pragma unroll
+      for (int r = 0; r < RR; r++) {
+        if (i < nrow[r]) {
+          const double d = prow[r][i] - t;
+          const bool hit = dprev[r] * d < 0.0;
+          const bool nh = hit && first[r] < 0;
+          first[r] = nh ? i - 1 : first[r];
+          if (MODE != 0) cnt[r] += hit ? 1u : 0u;
+          dprev[r] = d;
+        }
+      }
+    }
   }
 
   unsigned long long steps = 0;

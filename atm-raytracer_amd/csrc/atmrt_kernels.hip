@@ -783,8 +783,49 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
   }
 }
 
-// Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter over all objects
-// (TerrainData::from_lat_lon, utils.rs:72-88), then the step logic above.
+// Objects that can EVER be close to a sample of this ray (exact superset of Object::is_close over the whole ray).
+// Spherical model: every sample, lifted to the object's elevation, lies in the great-circle plane span(pos, dir) of the
+// ray's ground track, so |P - P_obj| >= distance of P_obj to that plane.  Azimuthal-equidistant model: the ground track
+// is a straight line of the flat map and z differences vanish, same argument with the line.  A millimetre of slack
+// covers the rounding of the recomputed sample positions.  Other models (ellipsoid geodesics, lat/lon-linear tracks):
+// no pre-filter.  Returns false when the list overflowed (the caller then tests every object, still exact).
+constexpr int CAND_CAP = 24;
+template <int CALC>
+static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n) {
+  n = 0;
+  if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
+  Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
+  for (int j = 0; j < f.n_objects; j++) {
+    const ObjectDev& o = f.objects[j];
+    Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
+    double dperp = dm_fabs(dot(rel, nrm));
+    double reach = dm_sqrt(o.close2) + 1.0e-3;
+    if (dperp <= reach) {
+      if (n >= CAND_CAP) return false;
+      cand[n++] = j;
+    }
+  }
+  return true;
+}
+
+// proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the candidates or over every object
+static __device__ __forceinline__ int close_ids(const Frame& f, const Earth& e, double lat, double lon, bool use_cand,
+                                                const int* cand, int ncand, int* ids, unsigned long long* counters) {
+  const LatLonTrig t = latlon_trig(e, lat, lon);
+  int n = 0;
+  const int total = use_cand ? ncand : f.n_objects;
+  for (int q = 0; q < total; q++) {
+    const int j = use_cand ? cand[q] : q;
+    if (object_is_close(e, f.objects[j], t)) {
+      if (n < CLOSE_CAP) ids[n++] = j;
+      else atomicOr(&counters[2], 2ull);
+    }
+  }
+  return n;
+}
+
+// Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
+// utils.rs:72-88), then the step logic above.
 template <bool FILL, int CALC>
 __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
                                                     PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
@@ -814,16 +855,10 @@ __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, co
       double lat0, lon0;
       coords_at_dist(e, c, 0.0, lat0, lon0);
       double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
-      int ids0[CLOSE_CAP], ids1[CLOSE_CAP];
-      int n0 = 0, n1 = 0;
-      {
-        const LatLonTrig t = latlon_trig(e, lat0, lon0);
-        for (int j = 0; j < f.n_objects; j++)
-          if (object_is_close(e, f.objects[j], t)) {
-            if (n0 < CLOSE_CAP) ids0[n0++] = j;
-            else atomicOr(&counters[2], 2ull);
-          }
-      }
+      int ids0[CLOSE_CAP], ids1[CLOSE_CAP], cand[CAND_CAP];
+      int ncand = 0;
+      const bool use_cand = ray_candidates<CALC>(f, e, c, cand, ncand);
+      int n0 = close_ids(f, e, lat0, lon0, use_cand, cand, ncand, ids0, counters), n1 = 0;
       double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh_ = alt, path_length = 0.0;
       for (int i = 1;; i++) {
@@ -835,15 +870,7 @@ __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, co
         double lat1, lon1;
         coords_at_dist(e, c, sx, lat1, lon1);
         double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
-        n1 = 0;
-        {
-          const LatLonTrig t = latlon_trig(e, lat1, lon1);
-          for (int j = 0; j < f.n_objects; j++)
-            if (object_is_close(e, f.objects[j], t)) {
-              if (n1 < CLOSE_CAP) ids1[n1++] = j;
-              else atomicOr(&counters[2], 2ull);
-            }
-        }
+        n1 = close_ids(f, e, lat1, lon1, use_cand, cand, ncand, ids1, counters);
         steps++;
         StepHits hits;
         hits.n = 0;

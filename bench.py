@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--dted-level", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--also-fast", action="store_true", help="also time the Fast generator and report it under 'fast'")
+    ap.add_argument("--objects", type=int, default=0, help="BASELINE config 5: add N scene objects (70%% frusta, 30%% billboards)")
+    ap.add_argument("--terrain-alpha", type=float, default=1.0)
     args = ap.parse_args()
 
     import numpy as np
@@ -93,6 +95,9 @@ def main():
     t_setup = time.perf_counter()
     cfg, tiles = synth.scene("headline", W, H, generator=args.generator, level=args.dted_level)
     cfg.params.col_begin, cfg.params.col_end = (c0, c1) if world > 1 else (0, 0)
+    cfg.params.terrain_alpha = args.terrain_alpha
+    if args.objects:
+        synth.add_objects(cfg, n_cyl=args.objects * 7 // 10, n_bill=args.objects - args.objects * 7 // 10)
     ctx = generators.Context(local_rank)
     terrain = generators.Terrain.from_tiles(tiles, ctx)
     log(f"[rank {rank}] scene ready in {time.perf_counter() - t_setup:.1f} s: {W}x{H}, columns [{c0},{c1}), "
@@ -198,7 +203,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"headline {W}x{H} panorama, 3x3 synthetic DTED level-{args.dted_level} tiles, step 100 m, max_distance 200 km, "
                                f"spherical Earth + US-76 refraction, fov 120, generator {args.generator}",
-                   "generator": args.generator, "width": W, "height": H, "parallelism": f"pixel-column tiles x{world}" if world > 1 else "single GPU"},
+                   "generator": args.generator, "width": W, "height": H, "objects": args.objects, "terrain_alpha": args.terrain_alpha, "parallelism": f"pixel-column tiles x{world}" if world > 1 else "single GPU"},
         "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
         "ray_steps_per_frame": marched / args.steps,
         "value_per_gpu": marched / elapsed / world,

@@ -176,3 +176,13 @@ def test_interpolating_rectilinear_with_objects_and_shard(gpu_ctx, oracle_det):
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert (got["color_tag"] == 1).sum() > 10
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
+def test_objects_in_a_line_overflow_the_candidate_list(gpu_ctx, oracle_det):
+    """40 objects on (almost) one azimuth: more than the 24 per-ray candidates of the pre-filter, so the affected rays fall
+    back to testing every object — results must not change."""
+    cfg, tiles = synth.scene("S2", 48, 24, generator="Rectilinear", terrain_alpha=0.5, max_distance=30_000.0, tilt=-2.0)
+    synth.add_objects(cfg, n_cyl=40, n_bill=0, dist=(500.0, 25_000.0), spread_deg=0.02, radius=(30.0, 60.0), height=(400.0, 900.0))
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert (got["color_tag"] == 1).sum() > 20
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))

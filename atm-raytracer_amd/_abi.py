@@ -70,6 +70,40 @@ class DevicePlanes(C.Structure):
                 ("normal", C.c_void_p)]
 
 
+class Coloring(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("palette", C.c_int32), ("water_level", C.c_double), ("max_distance", C.c_double),
+                ("ambient_light", C.c_double), ("light_dir", C.c_double * 3), ("has_fog", C.c_int32), ("_pad", C.c_int32),
+                ("fog_distance", C.c_double)]
+
+
+COLORING_SIMPLE, COLORING_SHADING = 0, 1
+PALETTES = {"Legacy": 0, "Improved": 1}
+
+
+def numpy_to_result(res):
+    """Inverse of result_to_numpy: an atmrt_result_t whose pointers borrow the numpy arrays (keep `res` alive)."""
+    import numpy as np
+    r = Result()
+    keep = {}
+
+    def ptr(key, dtype, ctype):
+        a = np.ascontiguousarray(res[key], dtype=dtype)
+        if a.size == 0:
+            a = np.zeros(1, dtype=dtype)
+        keep[key] = a
+        return a.ctypes.data_as(C.POINTER(ctype))
+
+    r.width, r.height = int(res["width"]), int(res["height"])
+    r.n_pixels, r.n_hits = r.width * r.height, int(res["n_hits"])
+    r.azimuth, r.elevation_angle = ptr("azimuth", np.float64, C.c_double), ptr("elevation_angle", np.float64, C.c_double)
+    r.hit_count, r.hit_offset = ptr("hit_count", np.uint32, C.c_uint32), ptr("hit_offset", np.uint64, C.c_uint64)
+    for k in ("lat", "lon", "distance", "elevation", "path_length", "normal", "rgba"):
+        setattr(r, k, ptr(k, np.float64, C.c_double))
+    r.color_tag = ptr("color_tag", np.uint32, C.c_uint32)
+    r.ray_steps = int(res["ray_steps"])
+    return r, keep
+
+
 class Timings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("profile_ms", C.c_double), ("paths_ms", C.c_double), ("intersect_ms", C.c_double),
                 ("march_ms", C.c_double), ("finalize_ms", C.c_double), ("pack_ms", C.c_double), ("ray_steps", C.c_uint64),

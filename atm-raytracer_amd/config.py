@@ -141,10 +141,37 @@ def _load_texture(path):
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGBA"), dtype=np.uint8))
 
 
+def _coloring(view):
+    """ConfColoring (params.rs:164-213) + fog_distance (:285): returned as the argument tuple of into_coloring."""
+    node = view.get("coloring")
+    fog = view.get("fog_distance")
+    conf = {"kind": _abi.COLORING_SHADING, "water_level": 0.0, "ambient_light": 0.4, "light_zenith_angle": 45.0, "light_dir": 0.0,
+            "palette": _abi.PALETTES["Improved"], "has_fog": 0 if fog is None else 1, "fog_distance": 0.0 if fog is None else float(fog)}
+    if node is None:
+        return conf  # ConfColoring::default = Shading{0, 0.4, 45, 0, Improved}, params.rs:203-213
+    (k, v), = node.items()
+    v = v or {}
+    conf["water_level"] = float(v.get("water_level", 0.0))
+    if k == "Simple":
+        conf["kind"] = _abi.COLORING_SIMPLE
+    elif k == "Shading":
+        conf["ambient_light"] = float(v.get("ambient_light", 0.4))
+        conf["light_zenith_angle"] = float(v.get("light_zenith_angle", 45.0))
+        conf["light_dir"] = float(v.get("light_dir", 0.0))
+        pal = v.get("palette", "Improved")
+        if pal not in _abi.PALETTES:
+            raise ConfigError(f"unknown palette {pal!r}")
+        conf["palette"] = _abi.PALETTES[pal]
+    else:
+        raise ConfigError(f"unknown coloring {k!r}")
+    return conf
+
+
 class Config:
-    """Config (params.rs:447-465) reduced to what reaches the generators."""
+    """Config (params.rs:447-465) reduced to what reaches the generators (+ the colouring of the renderer)."""
 
     def __init__(self):
+        self.coloring = _coloring({})
         self.params = _abi.Params()
         self.atmosphere = us76()
         self.objects = []
@@ -171,6 +198,7 @@ class Config:
             c.objects.append(o)
             c._keepalive.append(keep)
         view = d.get("view") or {}
+        c.coloring = _coloring(view)
         p.position = _position(view.get("position"))
         fr = view.get("frame") or {}
         p.frame.direction = float(fr.get("direction", 0.0))

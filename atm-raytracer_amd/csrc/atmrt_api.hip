@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "atmrt_kernels.h"
+#include "atmrt_render.h"
 
 using namespace atmrt;
 
@@ -77,6 +78,14 @@ struct atmrt_ctx {
   std::vector<double> xs;
   int n_t = 0, n_path_cap = 0;
   bool xs_dirty = true;
+
+  // last generated frame (for atmrt_draw_image)
+  bool last_valid = false, last_packed = false;
+  size_t last_npx = 0;
+  double last_alpha = 1.0;
+  DensePlanes last_dense{};
+  PackedHits last_hits{};
+  const uint64_t* last_offset = nullptr;
 
   std::vector<ObjectDev> objects;      // host image of the device table (altitude kind in _pad until k_resolve)
   std::vector<uint8_t> textures;       // RGBA8 pool
@@ -882,6 +891,13 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;
+  c->last_valid = true;
+  c->last_packed = want_packed || !f.opaque || f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR;
+  c->last_npx = (size_t)f.wl * f.h;
+  c->last_alpha = f.p.terrain_alpha;
+  c->last_dense = dense;
+  c->last_hits = packed;
+  c->last_offset = ws.hit_offset;
   return ATMRT_OK;
 }
 
@@ -991,6 +1007,44 @@ extern "C" int atmrt_generate_device(atmrt_ctx* c, const atmrt_device_planes_t* 
 extern "C" int atmrt_last_timings(atmrt_ctx* c, atmrt_timings_t* out) {
   if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
   *out = c->timings;
+  return ATMRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// renderer compositing + colouring
+// ---------------------------------------------------------------------------------------------
+extern "C" int atmrt_coloring_from_conf(const atmrt_params_t* params, int32_t kind, double water_level, double ambient_light,
+                                        double light_zenith_angle, double light_dir, int32_t palette, int32_t has_fog,
+                                        double fog_distance, atmrt_coloring_t* out) {
+  if (!params || !out) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (palette != ATMRT_PALETTE_LEGACY && palette != ATMRT_PALETTE_IMPROVED) return ATMRT_ERR_INVALID_ARGUMENT;
+  return coloring_from_conf(*params, kind, water_level, ambient_light, light_zenith_angle, light_dir, palette, has_fog,
+                            fog_distance, *out)
+             ? ATMRT_ERR_INVALID_ARGUMENT
+             : ATMRT_OK;
+}
+
+extern "C" int atmrt_draw_image_device(atmrt_ctx* c, const atmrt_coloring_t* coloring, uint8_t* rgb_device) {
+  if (!c || !coloring || !rgb_device) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_draw_image needs a frame: call atmrt_generate first");
+  if (coloring->kind != ATMRT_COLORING_SIMPLE && coloring->kind != ATMRT_COLORING_SHADING)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "unknown coloring kind %d", coloring->kind);
+  if (coloring->has_fog && !(coloring->fog_distance > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "fog_distance must be positive");
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_draw_image(c->last_npx, *coloring, c->last_alpha, c->last_packed, c->last_dense.hit_count, c->last_offset, c->last_hits,
+                    c->last_dense, rgb_device, c->stream);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_draw_image(atmrt_ctx* c, const atmrt_coloring_t* coloring, uint8_t* rgb) {
+  if (!c || !coloring || !rgb) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_draw_image needs a frame: call atmrt_generate first");
+  HIP_TRY(c, c->d_io.reserve(3 * c->last_npx + 256));
+  int rc = atmrt_draw_image_device(c, coloring, c->d_io.as<uint8_t>());
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpy(rgb, c->d_io.ptr, 3 * c->last_npx, hipMemcpyDeviceToHost));
   return ATMRT_OK;
 }
 

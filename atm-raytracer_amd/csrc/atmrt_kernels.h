@@ -147,6 +147,10 @@ void launch_multi_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
 void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense,
                             const PackedHits& packed, hipStream_t stream);
 
+void launch_draw_image(size_t n_pixels, const atmrt_coloring_t& col, double terrain_alpha, bool packed_valid,
+                       const uint32_t* hit_count, const uint64_t* hit_offset, const PackedHits& hits, const DensePlanes& dense,
+                       uint8_t* rgb, hipStream_t stream);
+
 // harness kernels (diagnostic subcommands of the reference)
 void launch_get_elev(const Frame& f, size_t n, const double* lat, const double* lon, double* elev, uint8_t* valid,
                      hipStream_t stream);

@@ -177,6 +177,25 @@ def make_generator(params: Params, terrain: Terrain) -> Generator:
     return {0: FastGenerator, 1: InterpolatingRectilinearGenerator, 2: RectilinearGenerator}[params.pod.generator](params, terrain)
 
 
+# ---- renderer::draw_image (src/renderer/mod.rs:385-414) on the device -----------------------------
+def into_coloring(lib, params_pod, conf):
+    """ConfColoring::into_coloring (params.rs:231-277) -> atmrt_coloring_t."""
+    col = _abi.Coloring()
+    rc = lib.atmrt_coloring_from_conf(C.byref(params_pod), conf["kind"], conf["water_level"], conf["ambient_light"],
+                                      conf["light_zenith_angle"], conf["light_dir"], conf["palette"], conf["has_fog"],
+                                      conf["fog_distance"], C.byref(col))
+    if rc != 0:
+        raise AtmrtError(rc, "invalid colouring configuration")
+    return col
+
+
+def draw_image(ctx, coloring, width, height):
+    """Composite the frame of the last generate() on `ctx` into an RGB8 image [height][width][3]."""
+    rgb = np.zeros((height, width, 3), dtype=np.uint8)
+    ctx.check(ctx.lib.atmrt_draw_image(ctx.handle, C.byref(coloring), rgb.ctypes.data))
+    return rgb
+
+
 # ---- integrator / sampler harnesses (ray_path.rs, atm_printer.rs, elev_profile.rs) -------------
 def ray_paths(ctx, h0, angles_deg, step, n_steps, straight=False):
     ang = np.ascontiguousarray(angles_deg, dtype=np.float64)

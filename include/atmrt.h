@@ -225,6 +225,31 @@ typedef struct atmrt_timings {
 } atmrt_timings_t;
 int atmrt_last_timings(atmrt_ctx* ctx, atmrt_timings_t* out);
 
+/* ---- renderer compositing + colouring on the device (src/renderer/mod.rs:367-414, src/coloring) -- */
+typedef enum atmrt_coloring_kind { ATMRT_COLORING_SIMPLE = 0, ATMRT_COLORING_SHADING = 1 } atmrt_coloring_kind;
+typedef enum atmrt_palette { ATMRT_PALETTE_LEGACY = 0, ATMRT_PALETTE_IMPROVED = 1 } atmrt_palette;
+/* `Coloring` (params.rs:216-229) + view.fog_distance (params.rs:305). */
+typedef struct atmrt_coloring {
+  int32_t kind;          /* atmrt_coloring_kind */
+  int32_t palette;       /* enum atmrt_palette; Shading only */
+  double water_level;
+  double max_distance;   /* Simple: frame.max_distance */
+  double ambient_light;  /* Shading */
+  double light_dir[3];   /* Shading: unit vector in the world frame */
+  int32_t has_fog;       /* view.fog_distance.is_some() */
+  int32_t _pad;
+  double fog_distance;
+} atmrt_coloring_t;
+/* ConfColoring::into_coloring (params.rs:231-277): light_zenith_angle / light_dir in degrees, relative to view.frame.direction. */
+int atmrt_coloring_from_conf(const atmrt_params_t* params, int32_t kind, double water_level, double ambient_light,
+                             double light_zenith_angle, double light_dir, int32_t palette, int32_t has_fog,
+                             double fog_distance, atmrt_coloring_t* out);
+/* renderer::draw_image for the frame of the last atmrt_generate / atmrt_generate_device call on this context (its trace
+ * points are still in HBM): rgb is host memory [height][width][3] of the shard, row-major like ImageBuffer. */
+int atmrt_draw_image(atmrt_ctx* ctx, const atmrt_coloring_t* coloring, uint8_t* rgb);
+/* Same, into caller-provided device memory (3 B per pixel instead of 88 B per pixel to gather across GPUs). */
+int atmrt_draw_image_device(atmrt_ctx* ctx, const atmrt_coloring_t* coloring, uint8_t* rgb_device);
+
 /* ---- integrator / sampler harnesses (the reference's diagnostic subcommands) ---------------- */
 /* output-ray-paths (src/ray_path.rs:65-103): for each elevation angle [deg] step the ray n_steps
  * times from height h0 with `step` metres; x and h are [n_angles][n_steps+1] including the start. */

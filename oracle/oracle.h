@@ -100,6 +100,11 @@ int oracle_generate(const atmrt_params_t* params, const atmrt_atmosphere_t* atm,
                     const atmrt_object_t* objects, size_t n_objects, int n_threads, atmrt_result_t* out);
 void oracle_result_free(atmrt_result_t* r);
 
+/* ---- renderer compositing + colouring (src/renderer/mod.rs:367-414, src/coloring) ---- */
+int oracle_coloring_from_conf(const atmrt_params_t* p, int32_t kind, double water_level, double ambient_light, double light_zenith_angle,
+                              double light_dir, int32_t palette, int32_t has_fog, double fog_distance, atmrt_coloring_t* out);
+int oracle_draw_image(const atmrt_result_t* r, const atmrt_coloring_t* c, uint8_t* rgb);
+
 /* ---- harnesses ---------------------------------------------------------------------------- */
 int oracle_ray_paths(const atmrt_params_t* params, const atmrt_atmosphere_t* atm, double h0, size_t n_angles,
                      const double* angles_deg, int straight, double step, size_t n_steps, double* x, double* h);

@@ -63,6 +63,9 @@ class Oracle:
         L.oracle_find_normal.argtypes = [C.POINTER(_abi.EarthModel), C.c_double, C.c_double, C.c_void_p]
         L.oracle_find_normal.restype = Vec3
         L.oracle_dted_read.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.POINTER(C.c_int16))]
+        L.oracle_coloring_from_conf.argtypes = [C.POINTER(_abi.Params), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                C.c_int32, C.c_int32, C.c_double, C.POINTER(_abi.Coloring)]
+        L.oracle_draw_image.argtypes = [C.POINTER(_abi.Result), C.POINTER(_abi.Coloring), C.c_void_p]
         L.oracle_ray_paths.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.Atmosphere), C.c_double, C.c_size_t, C.c_void_p,
                                        C.c_int, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
 
@@ -168,6 +171,21 @@ class Oracle:
         out = _abi.result_to_numpy(res)
         self.lib.oracle_result_free(C.byref(res))
         return out
+
+    def into_coloring(self, params, conf):
+        col = _abi.Coloring()
+        rc = self.lib.oracle_coloring_from_conf(C.byref(params), conf["kind"], conf["water_level"], conf["ambient_light"],
+                                                conf["light_zenith_angle"], conf["light_dir"], conf["palette"], conf["has_fog"],
+                                                conf["fog_distance"], C.byref(col))
+        assert rc == 0
+        return col
+
+    def draw_image(self, res, coloring):
+        r, keep = _abi.numpy_to_result(res)
+        rgb = np.zeros((res["height"], res["width"], 3), dtype=np.uint8)
+        assert self.lib.oracle_draw_image(C.byref(r), C.byref(coloring), rgb.ctypes.data) == 0
+        del keep
+        return rgb
 
     def ray_paths(self, params, h0, angles_deg, step, n_steps, straight=False, atm=None):
         atm = atm or self.us76()

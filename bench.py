@@ -78,9 +78,13 @@ def main():
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     dist = None
-    if world > 1:
+    # under torch.distributed.run the process group (RCCL) is always created, so a 1-rank launch exercises the same
+    # all-gather code path as N ranks; a plain `python bench.py` run has no process group
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-marching library has no CPU path")
@@ -113,7 +117,7 @@ def main():
     local = planes_for(wl)
     pod = _abi.DevicePlanes(**{k: v.data_ptr() for k, v in local.items()})
     gathered = None
-    if world > 1:
+    if distributed:
         gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in local.items()}
 
     def make_step(generator_name):
@@ -122,7 +126,7 @@ def main():
 
         def step():
             steps, _ms = gen.generate_device(pod)  # returns after the library's stream has drained
-            if world > 1:
+            if distributed:
                 for k, v in local.items():  # one RCCL all-gather per result plane
                     dist.all_gather_into_tensor(gathered[k], v)
             return steps, gen.last_timings()
@@ -132,7 +136,7 @@ def main():
         step = make_step(generator_name)
         for _ in range(warmup):
             step()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -142,11 +146,11 @@ def main():
             marched += s
             phase.append(tm)
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         stats = torch.tensor([elapsed, float(marched)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if distributed:
             tmax = stats[:1].clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             tot = stats[1:].clone()
@@ -221,8 +225,13 @@ def main():
             result["cpu_baseline"] = {"value": None, "error": repr(exc)}
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if distributed and rank == 0 and os.environ.get("ATMRT_BENCH_CHECK_GATHER"):
+        from atm_raytracer_amd.sharding import assemble
+        full = assemble(gathered["distance"].view((world,) + tuple(local["distance"].shape)))
+        ok = full.shape == (H, W) and torch.equal(full[:, c0:c1].nan_to_num(-1.0), local["distance"].nan_to_num(-1.0))
+        log(f"gathered image check: shape {tuple(full.shape)}, rank-0 shard matches: {bool(ok)}")
     ctx.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

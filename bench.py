@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--generator", default="Rectilinear", choices=["Rectilinear", "Fast"])
+    ap.add_argument("--generator", default="Rectilinear", choices=["Rectilinear", "Fast", "InterpolatingRectilinear"])
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--dted-level", type=int, default=2)
@@ -192,11 +192,16 @@ def main():
                "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
                "all_kernels": {per_kernel[k][0]: {"ms": mean(k), "algorithmic_GBps": per_kernel[k][1] / (mean(k) * 1e-3) / 1e9}
                                for k in keys if mean(k) > 0}}
-        if generator_name == "Rectilinear":
-            # secondary, honest figure: the march is FP64-VALU bound.  rocprofv3 SQ counters (profiles/r01/sq_counters_march.json):
-            # ~2,470 VALU instructions per ray-step, most of them FP64 at 16 lanes/clk/SIMD
-            out["fp64_valu"] = {"valu_instructions_per_ray_step": 2470, "valu_busy_frac_measured_r01": 0.73,
-                                "note": "not HBM-bound: 78 fp64 divisions + 12 pow per RK4 step; see DESIGN.md §4"}
+        sq_file = os.path.join(ROOT, "profiles", "r01", "sq_counters_v2.json")
+        if os.path.exists(sq_file):
+            # the compute side of the roofline, from the committed rocprofv3 SQ-counter passes of this command: fraction of
+            # cycles the SIMDs' VALU pipes are busy (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles) and active lanes
+            for name, v in json.load(open(sq_file)).items():
+                if kernel in name:
+                    out["valu"] = {"busy_frac": v["valu_busy_frac"], "lane_utilisation": v["lane_utilisation"],
+                                   "valu_lane_instructions_per_ray_step": v.get("valu_lane_instructions_per_ray_step"),
+                                   "source": "profiles/r01/sq_counters_v2.json",
+                                   "note": "k_rect_march is FP64-issue bound (12 n(h) evaluations with pow + 78 divisions per RK4 step), not HBM bound"}
         return out
 
     elapsed, marched, phase = timed(args.generator, args.steps, args.warmup)

@@ -5,7 +5,10 @@ struct against the compiled library (atmrt_abi_sizeof).
 """
 import ctypes as C
 
-MAX_ATM_LAYERS = 16
+MAX_ATM_FUNCTIONS = 8
+MAX_SPLINE_POINTS = 32
+TEMP_LINEAR, TEMP_SPLINE = 0, 1
+SPLINE_BOUNDARY = {"Natural": 0, "Derivatives": 1, "SecondDerivatives": 2}
 
 # atmrt_status
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_FORMAT, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
@@ -42,10 +45,16 @@ class Params(C.Structure):
                 ("col_end", C.c_uint16)]
 
 
+class TempFunction(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("boundary", C.c_int32), ("altitude", C.c_double), ("gradient", C.c_double),
+                ("bc", C.c_double * 2), ("n_points", C.c_int32), ("_pad", C.c_int32),
+                ("point_altitude", C.c_double * MAX_SPLINE_POINTS), ("point_temperature", C.c_double * MAX_SPLINE_POINTS)]
+
+
 class Atmosphere(C.Structure):
     _fields_ = [("pressure_altitude", C.c_double), ("pressure", C.c_double), ("temperature_altitude", C.c_double),
-                ("temperature", C.c_double), ("n_layers", C.c_int32), ("_pad", C.c_int32),
-                ("layer_altitude", C.c_double * MAX_ATM_LAYERS), ("layer_gradient", C.c_double * MAX_ATM_LAYERS)]
+                ("temperature", C.c_double), ("has_temperature_fixed_point", C.c_int32), ("n_functions", C.c_int32),
+                ("functions", TempFunction * MAX_ATM_FUNCTIONS)]
 
 
 class Object(C.Structure):

@@ -22,7 +22,7 @@ def build(force=False):
     """Compile libatmrt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
-    subprocess.run(["make", "-s", "-C", CSRC], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", CSRC], check=True)
     return LIB_PATH
 
 
@@ -74,7 +74,7 @@ def load():
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if L.atmrt_abi_version() != 1:
+    if L.atmrt_abi_version() != 2:
         raise ImportError("libatmrt.so ABI version mismatch")
     _lib = L
     return L

@@ -69,21 +69,39 @@ def us76():
     alts = [0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0]
     grads = [-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002]
     a.pressure_altitude, a.pressure = 0.0, 101325.0
-    a.temperature_altitude, a.temperature = 0.0, 288.15
-    a.n_layers = len(alts)
+    a.temperature_altitude, a.temperature, a.has_temperature_fixed_point = 0.0, 288.15, 1
+    a.n_functions = len(alts)
     for k, (h, g) in enumerate(zip(alts, grads)):
-        a.layer_altitude[k] = h
-        a.layer_gradient[k] = g
+        a.functions[k].kind, a.functions[k].altitude, a.functions[k].gradient = _abi.TEMP_LINEAR, h, g
     return a
 
 
-def _temperature_function(node):
+def _temperature_function(node, fn):
+    """`Linear{gradient}` or `Spline{boundary_condition, points}` (reference README.md:290-316) into an atmrt_temp_function_t."""
     if isinstance(node, dict) and len(node) == 1:
         (k, v), = node.items()
         if k == "Linear":
-            return float(v["gradient"])
+            fn.kind, fn.gradient = _abi.TEMP_LINEAR, float(v["gradient"])
+            return
         if k == "Spline":
-            raise ConfigError("Spline temperature functions are outside the hot-path scope (ATMRT_ERR_UNSUPPORTED)")
+            fn.kind = _abi.TEMP_SPLINE
+            bc = v.get("boundary_condition", "Natural")
+            if isinstance(bc, str):
+                if bc != "Natural":
+                    raise ConfigError(f"unknown boundary_condition {bc!r}")
+                fn.boundary = _abi.SPLINE_BOUNDARY["Natural"]
+            else:
+                (bk, bv), = bc.items()
+                if bk not in ("Derivatives", "SecondDerivatives") or len(bv) != 2:
+                    raise ConfigError(f"unknown boundary_condition {bc!r}")
+                fn.boundary, fn.bc[0], fn.bc[1] = _abi.SPLINE_BOUNDARY[bk], float(bv[0]), float(bv[1])
+            pts = v["points"]
+            if not 2 <= len(pts) <= _abi.MAX_SPLINE_POINTS:
+                raise ConfigError(f"a Spline needs 2..{_abi.MAX_SPLINE_POINTS} points")
+            fn.n_points = len(pts)
+            for i, (alt, temp) in enumerate(pts):
+                fn.point_altitude[i], fn.point_temperature[i] = float(alt), float(temp)
+            return
     raise ConfigError(f"unknown temperature function {node!r}")
 
 
@@ -93,19 +111,19 @@ def _atmosphere(node):  # AtmosphereDef schema, reference README.md:283-323
     a = _abi.Atmosphere()
     pr = node["pressure"]
     a.pressure_altitude, a.pressure = float(pr["altitude"]), float(pr["pressure"])
-    fixed = node.get("temperature_fixed_point")
-    if fixed is None:
-        raise ConfigError("temperature_fixed_point is required when every temperature function is Linear")
-    a.temperature_altitude, a.temperature = float(fixed["altitude"]), float(fixed["temperature"])
-    layers = [(0.0, _temperature_function(node["first_temperature_function"]))]
-    for nf in node.get("next_functions", []) or []:
-        layers.append((float(nf["altitude"]), _temperature_function(nf["function"])))
-    if len(layers) > _abi.MAX_ATM_LAYERS:
+    functions = [(0.0, node["first_temperature_function"])] + [(float(nf["altitude"]), nf["function"]) for nf in node.get("next_functions", []) or []]
+    if len(functions) > _abi.MAX_ATM_FUNCTIONS:
         raise ConfigError("too many temperature functions")
-    a.n_layers = len(layers)
-    for k, (h, g) in enumerate(layers):
-        a.layer_altitude[k] = h
-        a.layer_gradient[k] = g
+    a.n_functions = len(functions)
+    for k, (h, f) in enumerate(functions):
+        a.functions[k].altitude = h
+        _temperature_function(f, a.functions[k])
+    fixed = node.get("temperature_fixed_point")
+    has_spline = any(a.functions[k].kind == _abi.TEMP_SPLINE for k in range(a.n_functions))
+    if fixed is not None:
+        a.temperature_altitude, a.temperature, a.has_temperature_fixed_point = float(fixed["altitude"]), float(fixed["temperature"]), 1
+    elif not has_spline:
+        raise ConfigError("temperature_fixed_point is required when every temperature function is Linear")
     return a
 
 

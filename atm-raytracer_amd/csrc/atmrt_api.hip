@@ -415,20 +415,27 @@ extern "C" void atmrt_atmosphere_us76(atmrt_atmosphere_t* a) {
   a->pressure = 101325.0;
   a->temperature_altitude = 0.0;
   a->temperature = 288.15;
-  a->n_layers = 7;
+  a->has_temperature_fixed_point = 1;
+  a->n_functions = 7;
   for (int k = 0; k < 7; k++) {
-    a->layer_altitude[k] = alt[k];
-    a->layer_gradient[k] = lapse[k];
+    a->functions[k].kind = ATMRT_TEMP_LINEAR;
+    a->functions[k].altitude = alt[k];
+    a->functions[k].gradient = lapse[k];
   }
 }
 
 extern "C" int atmrt_set_atmosphere(atmrt_ctx* c, const atmrt_atmosphere_t* a) {
   if (!c || !a) return ATMRT_ERR_INVALID_ARGUMENT;
   AtmTable t;
-  if (atm_compile(*a, c->params.wavelength, t))
-    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere definition (n_layers=%d)", a->n_layers);
-  if (!(a->pressure > 0.0) || !(a->temperature > 0.0))
-    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "pressure and temperature fixed points must be positive");
+  static const char* why[] = {"", "bad function count or kind", "function altitudes must increase",
+                              "no temperature anchor: give temperature_fixed_point or a Spline", "bad spline points",
+                              "more than 64 temperature segments"};
+  int rc = atm_compile(*a, c->params.wavelength, t);
+  if (rc) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere definition: %s", why[-rc <= 5 ? -rc : 1]);
+  if (!(a->pressure > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "the pressure fixed point must be positive");
+  for (int k = 0; k < t.n; k++)
+    if (!(t.tb[k] > 0.0) || !(t.pb[k] > 0.0) || !std::isfinite(t.pb[k]))
+      return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "atmosphere definition yields a non-positive temperature or pressure");
   c->atm_def = *a;
   return ATMRT_OK;
 }
@@ -563,6 +570,7 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   f.h = p.height;
   f.opaque = (p.terrain_alpha == 1.0 && c->objects.empty()) ? 1 : 0;
   f.lattice = 0;
+  f.atm_cubic = atm_has_cubic(c->atm) ? 1 : 0;
   f.di0 = f.ei0 = 0;
   f.dir_step = f.elev_step = 0.0;
   *out = f;

@@ -41,16 +41,24 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // US Standard Atmosphere 1976 layers, hydrostatic ideal gas, Ciddor 1996 dry air).
 // ---------------------------------------------------------------------------------------------
 
+// The atmosphere compiled into SEGMENTS: a Linear function is one segment, a Spline contributes one segment per knot
+// interval (plus linear continuations outside its knots).  In a segment T(h) = tb + c1 dh + c2 dh^2 + c3 dh^3 with
+// dh = h - hb.  Linear segments (cubic == 0) use the closed-form hydrostatic pressure, cubic ones a 5-point
+// Gauss-Legendre quadrature of dh/T.
+#define ATMRT_MAX_ATM_SEGMENTS 64
 struct AtmTable {
   int32_t n;
   int32_t _pad;
-  double hb[ATMRT_MAX_ATM_LAYERS];    // reference altitude of layer k
-  double tb[ATMRT_MAX_ATM_LAYERS];    // temperature at hb
-  double pb[ATMRT_MAX_ATM_LAYERS];    // pressure at hb
-  double lapse[ATMRT_MAX_ATM_LAYERS]; // dT/dh
-  double from[ATMRT_MAX_ATM_LAYERS];  // layer k >= 1 applies for h >= from[k]
-  double expo[ATMRT_MAX_ATM_LAYERS];  // lapse != 0: -g0 M/(R lapse); lapse == 0: -g0 M/(R tb)
-  double k_refr;                      // (n - 1) = k_refr * (p/T) / Z
+  double hb[ATMRT_MAX_ATM_SEGMENTS];    // reference altitude of segment k
+  double tb[ATMRT_MAX_ATM_SEGMENTS];    // temperature at hb
+  double pb[ATMRT_MAX_ATM_SEGMENTS];    // pressure at hb
+  double lapse[ATMRT_MAX_ATM_SEGMENTS]; // c1 = dT/dh at hb
+  double from[ATMRT_MAX_ATM_SEGMENTS];  // segment k >= 1 applies for h >= from[k]
+  double expo[ATMRT_MAX_ATM_SEGMENTS];  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
+  double c2[ATMRT_MAX_ATM_SEGMENTS];
+  double c3[ATMRT_MAX_ATM_SEGMENTS];
+  int32_t cubic[ATMRT_MAX_ATM_SEGMENTS];
+  double k_refr;                        // (n - 1) = k_refr * (p/T) / Z
 };
 
 ATMRT_HD int atm_layer(const AtmTable& a, double h) {
@@ -59,49 +67,197 @@ ATMRT_HD int atm_layer(const AtmTable& a, double h) {
   return 0;
 }
 
-ATMRT_HD double atm_pressure_ratio(const AtmTable& a, int k, double h) {
-  if (a.lapse[k] != 0.0) {
-    double t = a.tb[k] + a.lapse[k] * (h - a.hb[k]);
-    return dm_pow(t / a.tb[k], a.expo[k]);
-  }
-  return dm_exp(a.expo[k] * (h - a.hb[k]));
+ATMRT_HD double seg_temperature(double tb, double c1, double c2, double c3, double dh) {
+  return tb + dh * (c1 + dh * (c2 + dh * c3));
 }
 
-// Atmosphere::from_def (params.rs:514): chain temperature and pressure outwards from the fixed points.
+// integral of dh'/T(h') from hb to hb + dh over a cubic segment: 5-point Gauss-Legendre on [0, dh]
+ATMRT_HD double seg_inv_t_integral(double tb, double c1, double c2, double c3, double dh) {
+  const double x1 = 0.5384693101056831, x2 = 0.9061798459386640;
+  const double w0 = 0.5688888888888889, w1 = 0.4786286704993665, w2 = 0.2369268850561891;
+  double half = 0.5 * dh;
+  double s = w0 / seg_temperature(tb, c1, c2, c3, half);
+  s += w1 / seg_temperature(tb, c1, c2, c3, half - half * x1);
+  s += w1 / seg_temperature(tb, c1, c2, c3, half + half * x1);
+  s += w2 / seg_temperature(tb, c1, c2, c3, half - half * x2);
+  s += w2 / seg_temperature(tb, c1, c2, c3, half + half * x2);
+  return half * s;
+}
+
+// p(h) / pb of segment k
+ATMRT_HD double seg_pressure_ratio(int cubic, double hb, double tb, double c1, double c2, double c3, double expo, double h) {
+  if (cubic) return dm_exp(expo * seg_inv_t_integral(tb, c1, c2, c3, h - hb));
+  if (c1 != 0.0) {
+    double t = tb + c1 * (h - hb);
+    return dm_pow(t / tb, expo);
+  }
+  return dm_exp(expo * (h - hb));
+}
+ATMRT_HD double atm_pressure_ratio(const AtmTable& a, int k, double h) {
+  return seg_pressure_ratio(a.cubic[k], a.hb[k], a.tb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+}
+ATMRT_HD double atm_seg_temperature(const AtmTable& a, int k, double h) {
+  if (a.cubic[k]) return seg_temperature(a.tb[k], a.lapse[k], a.c2[k], a.c3[k], h - a.hb[k]);
+  return a.tb[k] + a.lapse[k] * (h - a.hb[k]);
+}
+
+// Atmosphere::from_def (params.rs:514).  Returns 0, or a negative code: -1 bad counts, -2 altitudes not increasing,
+// -3 no temperature anchor (all Linear without a fixed point), -4 bad spline, -5 too many segments.
 ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTable& out) {
   const double gmr = 9.80665 * 0.0289644 / 8.31432;
-  int n = def.n_layers;
-  if (n < 1 || n > ATMRT_MAX_ATM_LAYERS) return -1;
-  out.n = n;
+  const int nf = def.n_functions;
+  if (nf < 1 || nf > ATMRT_MAX_ATM_FUNCTIONS) return -1;
+  for (int k = 0; k < ATMRT_MAX_ATM_SEGMENTS; k++) {
+    out.hb[k] = out.tb[k] = out.pb[k] = out.lapse[k] = out.from[k] = out.expo[k] = out.c2[k] = out.c3[k] = 0.0;
+    out.cubic[k] = 0;
+  }
   out._pad = 0;
-  for (int k = 0; k < ATMRT_MAX_ATM_LAYERS; k++) {
-    out.hb[k] = out.tb[k] = out.pb[k] = out.lapse[k] = out.from[k] = out.expo[k] = 0.0;
+  for (int j = 2; j < nf; j++)
+    if (!(def.functions[j].altitude > def.functions[j - 1].altitude)) return -2;
+  // ---- segments, function by function; `owner` remembers which function a segment belongs to
+  int n = 0;
+  int owner[ATMRT_MAX_ATM_SEGMENTS];
+  int first_seg[ATMRT_MAX_ATM_FUNCTIONS + 1];
+  bool anchored[ATMRT_MAX_ATM_FUNCTIONS];
+  for (int j = 0; j < nf; j++) {
+    const atmrt_temp_function_t& fn = def.functions[j];
+    const bool has_lo = j > 0, has_hi = j + 1 < nf;
+    const double lo = has_lo ? fn.altitude : 0.0, hi = has_hi ? def.functions[j + 1].altitude : 0.0;
+    first_seg[j] = n;
+    anchored[j] = false;
+    if (fn.kind == ATMRT_TEMP_LINEAR) {
+      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
+      owner[n] = j;
+      out.from[n] = lo;
+      out.lapse[n] = fn.gradient;
+      n++;
+      continue;
+    }
+    if (fn.kind != ATMRT_TEMP_SPLINE) return -1;
+    const int np = fn.n_points;
+    if (np < 2 || np > ATMRT_MAX_SPLINE_POINTS) return -4;
+    const double* x = fn.point_altitude;
+    const double* y = fn.point_temperature;
+    for (int i = 1; i < np; i++)
+      if (!(x[i] > x[i - 1])) return -4;
+    // second derivatives m[i] of the interpolating cubic spline (Thomas algorithm)
+    double m[ATMRT_MAX_SPLINE_POINTS], cp[ATMRT_MAX_SPLINE_POINTS], dp[ATMRT_MAX_SPLINE_POINTS];
+    {
+      double b0, c0, d0, an, bn, dn;
+      if (fn.boundary == ATMRT_SPLINE_DERIVATIVES) {
+        double h0 = x[1] - x[0], hn = x[np - 1] - x[np - 2];
+        b0 = 2.0 * h0; c0 = h0; d0 = 6.0 * ((y[1] - y[0]) / h0 - fn.bc[0]);
+        an = hn; bn = 2.0 * hn; dn = 6.0 * (fn.bc[1] - (y[np - 1] - y[np - 2]) / hn);
+      } else {
+        b0 = 1.0; c0 = 0.0; d0 = fn.boundary == ATMRT_SPLINE_SECOND_DERIVATIVES ? fn.bc[0] : 0.0;
+        an = 0.0; bn = 1.0; dn = fn.boundary == ATMRT_SPLINE_SECOND_DERIVATIVES ? fn.bc[1] : 0.0;
+      }
+      cp[0] = c0 / b0;
+      dp[0] = d0 / b0;
+      for (int i = 1; i < np; i++) {
+        double ai, bi, ci, di;
+        if (i < np - 1) {
+          double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+          ai = hl; bi = 2.0 * (hl + hr); ci = hr;
+          di = 6.0 * ((y[i + 1] - y[i]) / hr - (y[i] - y[i - 1]) / hl);
+        } else {
+          ai = an; bi = bn; ci = 0.0; di = dn;
+        }
+        double den = bi - ai * cp[i - 1];
+        cp[i] = ci / den;
+        dp[i] = (di - ai * dp[i - 1]) / den;
+      }
+      m[np - 1] = dp[np - 1];
+      for (int i = np - 2; i >= 0; i--) m[i] = dp[i] - cp[i] * m[i + 1];
+    }
+    // linear continuation below the first knot
+    if (!has_lo || lo < x[0]) {
+      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
+      double hh = x[1] - x[0];
+      owner[n] = j;
+      out.from[n] = lo;
+      out.hb[n] = x[0];
+      out.tb[n] = y[0];
+      out.lapse[n] = (y[1] - y[0]) / hh - hh * (2.0 * m[0] + m[1]) / 6.0; // S'(x0)
+      n++;
+    }
+    for (int i = 0; i + 1 < np; i++) {
+      if (has_hi && x[i] >= hi) break;          // interval entirely above this function's range
+      if (has_lo && x[i + 1] <= lo) continue;   // interval entirely below it
+      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
+      double hh = x[i + 1] - x[i];
+      owner[n] = j;
+      out.from[n] = (has_lo && lo > x[i]) ? lo : x[i];
+      out.hb[n] = x[i];
+      out.tb[n] = y[i];
+      out.lapse[n] = (y[i + 1] - y[i]) / hh - hh * (2.0 * m[i] + m[i + 1]) / 6.0;
+      out.c2[n] = m[i] / 2.0;
+      out.c3[n] = (m[i + 1] - m[i]) / (6.0 * hh);
+      out.cubic[n] = 1;
+      n++;
+    }
+    // linear continuation above the last knot
+    if (!has_hi || hi > x[np - 1]) {
+      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
+      double hh = x[np - 1] - x[np - 2];
+      owner[n] = j;
+      out.from[n] = x[np - 1];
+      out.hb[n] = x[np - 1];
+      out.tb[n] = y[np - 1];
+      out.lapse[n] = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0; // S'(x_last)
+      n++;
+    }
+    anchored[j] = true;
   }
-  for (int k = 0; k < n; k++) {
-    out.lapse[k] = def.layer_gradient[k];
-    out.from[k] = k == 0 ? 0.0 : def.layer_altitude[k];
-    if (k >= 2 && !(out.from[k] > out.from[k - 1])) return -1;
+  first_seg[nf] = n;
+  out.n = n;
+  out.from[0] = 0.0; // segment 0 extends to -inf
+  // ---- absolute temperature of the Linear functions: the fixed point, else continuity with an anchored neighbour
+  if (def.has_temperature_fixed_point) {
+    int jt = 0;
+    for (int j = nf - 1; j >= 1; j--)
+      if (def.temperature_altitude >= def.functions[j].altitude) { jt = j; break; }
+    if (def.functions[jt].kind == ATMRT_TEMP_LINEAR && !anchored[jt]) {
+      int k = first_seg[jt];
+      out.hb[k] = jt == 0 ? def.temperature_altitude : out.from[k];
+      out.tb[k] = def.temperature - out.lapse[k] * (def.temperature_altitude - out.hb[k]);
+      anchored[jt] = true;
+    }
   }
-  int jt = 0;
-  for (int k = n - 1; k >= 1; k--)
-    if (def.temperature_altitude >= out.from[k]) { jt = k; break; }
-  out.hb[jt] = jt == 0 ? def.temperature_altitude : out.from[jt];
-  out.tb[jt] = def.temperature - out.lapse[jt] * (def.temperature_altitude - out.hb[jt]);
-  for (int k = jt + 1; k < n; k++) {
-    out.hb[k] = out.from[k];
-    out.tb[k] = out.tb[k - 1] + out.lapse[k - 1] * (out.from[k] - out.hb[k - 1]);
+  bool any = false;
+  for (int j = 0; j < nf; j++) any = any || anchored[j];
+  if (!any) return -3;
+  for (int pass = 0; pass < nf; pass++) {
+    for (int j = 0; j < nf; j++) {
+      if (anchored[j]) continue;
+      int k = first_seg[j];
+      if (j > 0 && anchored[j - 1]) { // continuous with the function below at this function's start altitude
+        int kl = first_seg[j] - 1;
+        out.hb[k] = out.from[k];
+        out.tb[k] = atm_seg_temperature(out, kl, out.from[k]);
+        anchored[j] = true;
+      } else if (j + 1 < nf && anchored[j + 1]) { // continuous with the function above at its start altitude
+        int ku = first_seg[j + 1];
+        double top = def.functions[j + 1].altitude;
+        out.hb[k] = j == 0 ? top : out.from[k];
+        out.tb[k] = atm_seg_temperature(out, ku, top) - out.lapse[k] * (top - out.hb[k]);
+        anchored[j] = true;
+      }
+    }
   }
-  for (int k = jt - 1; k >= 0; k--) {
-    out.hb[k] = k == 0 ? out.from[1] : out.from[k];
-    out.tb[k] = out.tb[k + 1] - out.lapse[k] * (out.from[k + 1] - out.hb[k]);
-  }
-  for (int k = 0; k < n; k++) out.expo[k] = out.lapse[k] != 0.0 ? -gmr / out.lapse[k] : -gmr / out.tb[k];
-  int jp = 0;
-  for (int k = n - 1; k >= 1; k--)
-    if (def.pressure_altitude >= out.from[k]) { jp = k; break; }
+  for (int k = 0; k < n; k++)
+    out.expo[k] = out.cubic[k] ? -gmr : (out.lapse[k] != 0.0 ? -gmr / out.lapse[k] : -gmr / out.tb[k]);
+  // ---- pressure: chain outwards from the pressure fixed point
+  int jp = atm_layer(out, def.pressure_altitude);
   out.pb[jp] = def.pressure / atm_pressure_ratio(out, jp, def.pressure_altitude);
-  for (int k = jp + 1; k < n; k++) out.pb[k] = out.pb[k - 1] * atm_pressure_ratio(out, k - 1, out.from[k]);
-  for (int k = jp - 1; k >= 0; k--) out.pb[k] = out.pb[k + 1] / atm_pressure_ratio(out, k, out.from[k + 1]);
+  for (int k = jp + 1; k < n; k++) {
+    double pk = out.pb[k - 1] * atm_pressure_ratio(out, k - 1, out.from[k]); // p at the boundary, from below
+    out.pb[k] = pk / atm_pressure_ratio(out, k, out.from[k]);
+  }
+  for (int k = jp - 1; k >= 0; k--) {
+    double pk = out.pb[k + 1] * atm_pressure_ratio(out, k + 1, out.from[k + 1]); // p at the boundary, from above
+    out.pb[k] = pk / atm_pressure_ratio(out, k, out.from[k + 1]);
+  }
   {
     const double k0 = 238.0185, k1 = 5792105.0, k2 = 57.362, k3 = 167917.0;
     const double xco2 = 450.0, pr1 = 101325.0, tr1 = 288.15, za = 0.9995922115, r = 8.314472;
@@ -116,31 +272,44 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
   return 0;
 }
 
-ATMRT_HD double atm_temperature(const AtmTable& a, double h) {
-  int k = atm_layer(a, h);
-  return a.tb[k] + a.lapse[k] * (h - a.hb[k]);
-}
+ATMRT_HD double atm_temperature(const AtmTable& a, double h) { return atm_seg_temperature(a, atm_layer(a, h), h); }
 ATMRT_HD double atm_pressure(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
   return a.pb[k] * atm_pressure_ratio(a, k, h);
 }
 
-// Environment::n(h) for a point known to lie in the layer with these parameters
-ATMRT_HD double refr_n_layer(double k_refr, double hb, double tb, double pb, double lapse, double expo, double h) {
+// Ciddor's (n - 1) = K (p/T) / Z for dry air
+ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
-  double temp = tb + lapse * (h - hb);
-  double ratio = lapse != 0.0 ? dm_pow(temp / tb, expo) : dm_exp(expo * (h - hb));
-  double p = pb * ratio;
   double t = temp - 273.15;
   double pt = p / temp;
   double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
   return 1.0 + k_refr * pt / z;
 }
 
+// a knot interval of a Spline temperature function
+ATMRT_HD double refr_n_cubic_segment(double k_refr, double hb, double tb, double pb, double c1, double c2, double c3, double expo, double h) {
+  double temp = seg_temperature(tb, c1, c2, c3, h - hb);
+  double p = pb * dm_exp(expo * seg_inv_t_integral(tb, c1, c2, c3, h - hb));
+  return refr_from_tp(k_refr, temp, p);
+}
+
+// Environment::n(h) for a point known to lie in the segment with these parameters.  CUBIC = false instantiates only the
+// closed-form path of Linear functions: the stepping kernels are compiled in both variants and the host picks by
+// whether the atmosphere has Spline segments (inlining the quadrature path twelve times per RK4 step costs 9 % on US-76).
+template <bool CUBIC = true>
+ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3,
+                             double expo, double h) {
+  if (CUBIC && cubic) return refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h);
+  double temp = tb + lapse * (h - hb);
+  double ratio = lapse != 0.0 ? dm_pow(temp / tb, expo) : dm_exp(expo * (h - hb));
+  return refr_from_tp(k_refr, temp, pb * ratio);
+}
+
 // Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).
 ATMRT_HD double refr_n(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
-  return refr_n_layer(a.k_refr, a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.expo[k], h);
+  return refr_n_layer(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
 }
 ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   const double eps = 0.01;
@@ -152,23 +321,26 @@ ATMRT_HD double refr_dn(const AtmTable& a, double h) {
 // Same values as refr_n, organised for the wavefront: `hint` is the layer of the previous evaluation.  When every
 // active lane is still inside that layer (the normal case: rays stay below 11 km) the layer search is two compares and
 // the layer parameters are wave-uniform scalars; otherwise the lane falls back to the full search and a gather.
+template <bool CUBIC>
 ATMRT_HD double refr_n_hint(const AtmTable& a, double h, int& hint) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   const bool ok = (ku == 0 || h >= a.from[ku]) && (ku == a.n - 1 || h < a.from[ku + 1]);
-  if (__all(ok)) return refr_n_layer(a.k_refr, a.hb[ku], a.tb[ku], a.pb[ku], a.lapse[ku], a.expo[ku], h);
+  if (__all(ok))
+    return refr_n_layer<CUBIC>(a.k_refr, a.cubic[ku], a.hb[ku], a.tb[ku], a.pb[ku], a.lapse[ku], a.c2[ku], a.c3[ku], a.expo[ku], h);
   const int k = ok ? ku : atm_layer(a, h);
   hint = k;
-  return refr_n_layer(a.k_refr, a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.expo[k], h);
+  return refr_n_layer<CUBIC>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
 #else
   (void)hint;
   return refr_n(a, h);
 #endif
 }
+template <bool CUBIC>
 ATMRT_HD double refr_dn_hint(const AtmTable& a, double h, int& hint) {
   const double eps = 0.01;
-  double n1 = refr_n_hint(a, h - eps, hint);
-  double n2 = refr_n_hint(a, h + eps, hint);
+  double n1 = refr_n_hint<CUBIC>(a, h - eps, hint);
+  double n2 = refr_n_hint<CUBIC>(a, h + eps, hint);
   return (n2 - n1) / (2.0 * eps);
 }
 
@@ -500,15 +672,16 @@ ATMRT_HD void stepper_init(Stepper& s, bool spherical, double radius, double h0,
   }
 }
 
+template <bool CUBIC>
 ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b, int& hint) {
   if (spherical) {
     double h = a - radius;
-    double n = refr_n_hint(atm, h, hint);
-    double dn = refr_dn_hint(atm, h, hint);
+    double n = refr_n_hint<CUBIC>(atm, h, hint);
+    double dn = refr_dn_hint<CUBIC>(atm, h, hint);
     return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
   }
-  double n = refr_n_hint(atm, a, hint);
-  double dn = refr_dn_hint(atm, a, hint);
+  double n = refr_n_hint<CUBIC>(atm, a, hint);
+  double dn = refr_dn_hint<CUBIC>(atm, a, hint);
   return (1.0 + b * b) * dn / n;
 }
 
@@ -557,15 +730,22 @@ ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, b
   return out;
 }
 
+template <bool CUBIC>
 struct SerialAccel {
   const AtmTable& atm;
   ATMRT_HD double operator()(bool spherical, double radius, double a, double b, int& hint) const {
-    return ray_accel(atm, spherical, radius, a, b, hint);
+    return ray_accel<CUBIC>(atm, spherical, radius, a, b, hint);
   }
 };
+template <bool CUBIC = true>
 ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight,
                                double step) {
-  return stepper_next_with(s, spherical, radius, straight, step, SerialAccel{atm});
+  return stepper_next_with(s, spherical, radius, straight, step, SerialAccel<CUBIC>{atm});
+}
+ATMRT_HD bool atm_has_cubic(const AtmTable& a) {
+  for (int k = 0; k < a.n; k++)
+    if (a.cubic[k]) return true;
+  return false;
 }
 
 // calc_dist, utils.rs:42-53

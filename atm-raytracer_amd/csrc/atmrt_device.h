@@ -1,0 +1,209 @@
+// atmrt_device.h — device-side helpers shared by the two kernel translation units (atmrt_kernels.hip: Fast,
+// InterpolatingRectilinear, renderer, scan, harnesses; atmrt_march.hip: Rectilinear march and general tracer).
+#pragma once
+
+#include "atmrt_kernels.h"
+
+namespace atmrt {
+
+static __device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// TracePoint (generators/mod.rs:21-30) of a terrain hit
+struct TracePointDev {
+  double lat, lon, distance, elevation, path_length;
+  Vec3 normal;
+};
+
+// One bracketing pair -> interpolated terrain TracePoint (utils.rs:222-236 with :108-125)
+static __device__ TracePointDev terrain_trace_point(const Frame& f, const Earth& e, double lat0, double lon0, double te0, double re0,
+                                                    double dist0, double pl0, double lat1, double lon1, double te1,
+                                                    double re1, double dist1, double pl1) {
+  double diff1 = re0 - te0;
+  double diff2 = re1 - te1;
+  double prop = diff1 / (diff1 - diff2);
+  Vec3 n0 = v3(0.0, 0.0, 0.0), n1 = n0;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) { // one instantiation of find_normal for both bracketing samples
+    Vec3 n = find_normal(e, f.tv, k == 0 ? lat0 : lat1, k == 0 ? lon0 : lon1);
+    if (k == 0) n0 = n;
+    else n1 = n;
+  }
+  TracePointDev tp;
+  tp.lat = lerp_ts(lat0, lat1, prop);
+  tp.lon = lerp_ts(lon0, lon1, prop);
+  tp.elevation = lerp_ts(te0, te1, prop);
+  tp.normal = v3(lerp_ts(n0.x, n1.x, prop), lerp_ts(n0.y, n1.y, prop), lerp_ts(n0.z, n1.z, prop));
+  tp.distance = lerp_ts(dist0, dist1, prop);
+  tp.path_length = lerp_ts(pl0, pl1, prop);
+  return tp;
+}
+
+static __device__ __forceinline__ void store_dense(const DensePlanes& o, size_t p, size_t plane, const TracePointDev& tp) {
+  o.lat[p] = tp.lat;
+  o.lon[p] = tp.lon;
+  o.distance[p] = tp.distance;
+  o.elevation[p] = tp.elevation;
+  o.path_length[p] = tp.path_length;
+  o.normal[p] = tp.normal.x;
+  o.normal[plane + p] = tp.normal.y;
+  o.normal[2 * plane + p] = tp.normal.z;
+}
+static __device__ __forceinline__ void store_dense_miss(const DensePlanes& o, size_t p, size_t plane) {
+  double n = qnan();
+  o.lat[p] = n;
+  o.lon[p] = n;
+  o.distance[p] = n;
+  o.elevation[p] = n;
+  o.path_length[p] = n;
+  o.normal[p] = n;
+  o.normal[plane + p] = n;
+  o.normal[2 * plane + p] = n;
+}
+static __device__ __forceinline__ void store_packed(const PackedHits& o, uint64_t k, const TracePointDev& tp, double alpha) {
+  o.lat[k] = tp.lat;
+  o.lon[k] = tp.lon;
+  o.distance[k] = tp.distance;
+  o.elevation[k] = tp.elevation;
+  o.path_length[k] = tp.path_length;
+  o.normal[3 * k] = tp.normal.x;
+  o.normal[3 * k + 1] = tp.normal.y;
+  o.normal[3 * k + 2] = tp.normal.z;
+  o.color_tag[k] = ATMRT_COLOR_TERRAIN;
+  o.rgba[4 * k] = 0.0;
+  o.rgba[4 * k + 1] = 0.0;
+  o.rgba[4 * k + 2] = 0.0;
+  o.rgba[4 * k + 3] = alpha;
+}
+
+// wave-wide sum of a 64-bit count, result valid in lane 0
+static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// The DirectionalCalc kind is a compile-time constant in the heavy kernels, so only one of the four
+// calculators (AzEq / FlDs / Spherical / Ellipsoid-Vincenty) is instantiated per kernel variant.
+template <int CALC>
+static __device__ __forceinline__ Earth earth_for(const Frame& f) {
+  Earth e = f.earth;
+  e.calc = CALC;
+  return e;
+}
+// the stepping kernels exist with and without the Spline (cubic-segment) path of n(h)
+#define ATMRT_LAUNCH_MARCH(MODE, ...)                                                   \
+  do {                                                                                  \
+    if (f.atm_cubic) hipLaunchKernelGGL((k_rect_march<MODE, CALC, true>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((k_rect_march<MODE, CALC, false>), __VA_ARGS__);            \
+  } while (0)
+#define ATMRT_LAUNCH_TRACE(FILL, ...)                                                   \
+  do {                                                                                  \
+    if (f.atm_cubic) hipLaunchKernelGGL((k_rect_trace<FILL, CALC, true>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((k_rect_trace<FILL, CALC, false>), __VA_ARGS__);            \
+  } while (0)
+#define ATMRT_DISPATCH_CALC(calc, STMT)                  \
+  switch (calc) {                                        \
+    case 0: { constexpr int CALC = 0; STMT; } break;     \
+    case 1: { constexpr int CALC = 1; STMT; } break;     \
+    case 2: { constexpr int CALC = 2; STMT; } break;     \
+    default: { constexpr int CALC = 3; STMT; } break;    \
+  }
+
+// ---------------------------------------------------------------------------------------------
+// General tracer (shared part): scenes with objects (and any terrain_alpha).  get_single_pixel in full
+// (utils.rs:201-289): per step the terrain sign change plus the collisions with every object that is
+// close to either sample, stable-sorted by prop; stop after the step if anything opaque was hit.
+// Two passes (count -> exclusive scan -> fill) because the trace-point lists have variable length.
+// ---------------------------------------------------------------------------------------------
+constexpr int STEP_CANDIDATES = 12; // trace points one step may produce here (terrain + 4 per object); more sets the error flag
+constexpr int CLOSE_CAP = 8;        // Rectilinear: objects close to one sample kept per lane; more sets the error flag
+
+struct StepHits {
+  int n;
+  bool finish;
+  int kind[STEP_CANDIDATES]; // -1 terrain, else object index
+  Collision col[STEP_CANDIDATES];
+};
+
+static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int kind, const Collision* c,
+                                                 unsigned long long* counters) {
+  if (sh.n >= STEP_CANDIDATES) {
+    atomicOr(&counters[2], 1ull);
+    return;
+  }
+  int j = sh.n; // step_result.sort_by(prop) is stable: insert behind every element with prop <= new prop
+  while (j > 0 && sh.col[j - 1].prop > prop) {
+    sh.col[j] = sh.col[j - 1];
+    sh.kind[j] = sh.kind[j - 1];
+    j--;
+  }
+  sh.kind[j] = kind;
+  sh.col[j].prop = prop;
+  if (c) {
+    sh.col[j].normal = c->normal;
+    for (int q = 0; q < 4; q++) sh.col[j].color[q] = c->color[q];
+  }
+  sh.n++;
+}
+
+// collisions of one object with the segment, utils.rs:251-278
+static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2,
+                                                   unsigned long long* counters) {
+  Collision col[4];
+  int nc = object_collision(f.objects[idx], f.textures, pos1, pos2, col);
+  for (int q = 0; q < nc; q++) {
+    if (col[q].color[3] == 0.0) continue;
+    step_push(sh, col[q].prop, idx, &col[q], counters);
+    if (col[q].color[3] == 1.0) {
+      sh.finish = true;
+      break;
+    }
+  }
+}
+
+// emit the sorted trace points of one step (fill pass).  Terrain points are finished later by the
+// *_finalize_list kernels (they need find_normal); object points are complete here (utils.rs:261-272).
+static __device__ __forceinline__ void step_emit(const StepHits& sh, const PackedHits& packed, uint32_t* list_step,
+                                                 uint32_t* list_pixel, uint64_t& k, uint32_t pixel, int step_index,
+                                                 double lat0, double lon0, double re0, double d0, double pl0, double lat1,
+                                                 double lon1, double re1, double d1, double pl1) {
+  for (int j = 0; j < sh.n; j++, k++) {
+    list_step[k] = (uint32_t)step_index;
+    list_pixel[k] = pixel;
+    if (sh.kind[j] < 0) {
+      packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
+      continue;
+    }
+    double prop = sh.col[j].prop;
+    packed.lat[k] = lerp_ts(lat0, lat1, prop);
+    packed.lon[k] = lerp_ts(lon0, lon1, prop);
+    packed.distance[k] = lerp_ts(d0, d1, prop);
+    packed.elevation[k] = lerp_ts(re0, re1, prop); // object hits report the RAY elevation (utils.rs:268)
+    packed.path_length[k] = lerp_ts(pl0, pl1, prop);
+    packed.normal[3 * k] = sh.col[j].normal.x;
+    packed.normal[3 * k + 1] = sh.col[j].normal.y;
+    packed.normal[3 * k + 2] = sh.col[j].normal.z;
+    packed.color_tag[k] = ATMRT_COLOR_RGBA;
+    for (int q = 0; q < 4; q++) packed.rgba[4 * k + q] = sh.col[j].color[q];
+  }
+}
+
+
+// Rectilinear record: ray elevation and path length at the two samples that bracket a crossing (planar arrays)
+struct RectRec {
+  double* re0;
+  double* pl0;
+  double* re1;
+  double* pl1;
+};
+static inline RectRec carve_rec(double* base, size_t n) {
+  RectRec r;
+  r.re0 = base;
+  r.pl0 = base + n;
+  r.re1 = base + 2 * n;
+  r.pl1 = base + 3 * n;
+  return r;
+}
+
+} // namespace atmrt

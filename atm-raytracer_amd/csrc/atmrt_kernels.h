@@ -26,6 +26,7 @@ struct Frame {
   // InterpolatingRectilinear: the frame is the angular lattice of Cache::get_pixel (interpolating_rectilinear.rs:80-107):
   // column x has azimuth (di0 + x) * dir_step, row y has elevation (ei0 + y) * elev_step (radians)
   int32_t lattice;
+  int32_t atm_cubic;        // the atmosphere has Spline segments: launch the kernel variants that carry the quadrature path
   int32_t di0, ei0;
   double dir_step, elev_step;
 };
@@ -150,6 +151,12 @@ void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, cons
 void launch_draw_image(size_t n_pixels, const atmrt_coloring_t& col, double terrain_alpha, bool packed_valid,
                        const uint32_t* hit_count, const uint64_t* hit_offset, const PackedHits& hits, const DensePlanes& dense,
                        uint8_t* rgb, hipStream_t stream);
+
+void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
+void launch_rect_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                            hipStream_t stream);
+void launch_dense_from_packed(const Frame& f, Workspace& ws, const PackedHits& packed, const DensePlanes& dense, int fast_angles,
+                              hipStream_t stream);
 
 // harness kernels (diagnostic subcommands of the reference)
 void launch_get_elev(const Frame& f, size_t n, const double* lat, const double* lon, double* elev, uint8_t* valid,

@@ -10,103 +10,10 @@
 //   k_fast_intersect  phase C: sign-change scan of get_single_pixel     (utils.rs:211-240)
 //   k_fast_finalize   TracePoint at the bracketing samples only   (utils.rs:108-125, 15-40)
 // Rectilinear generator (rectilinear.rs:102-186): k_rect_march, one ray per lane.
-#include "atmrt_kernels.h"
+#include "atmrt_device.h"
 #include "atmrt_render.h"
 
 namespace atmrt {
-
-static __device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
-
-// TracePoint (generators/mod.rs:21-30) of a terrain hit
-struct TracePointDev {
-  double lat, lon, distance, elevation, path_length;
-  Vec3 normal;
-};
-
-// One bracketing pair -> interpolated terrain TracePoint (utils.rs:222-236 with :108-125)
-static __device__ TracePointDev terrain_trace_point(const Frame& f, const Earth& e, double lat0, double lon0, double te0, double re0,
-                                                    double dist0, double pl0, double lat1, double lon1, double te1,
-                                                    double re1, double dist1, double pl1) {
-  double diff1 = re0 - te0;
-  double diff2 = re1 - te1;
-  double prop = diff1 / (diff1 - diff2);
-  Vec3 n0 = v3(0.0, 0.0, 0.0), n1 = n0;
-#pragma unroll 1
-  for (int k = 0; k < 2; k++) { // one instantiation of find_normal for both bracketing samples
-    Vec3 n = find_normal(e, f.tv, k == 0 ? lat0 : lat1, k == 0 ? lon0 : lon1);
-    if (k == 0) n0 = n;
-    else n1 = n;
-  }
-  TracePointDev tp;
-  tp.lat = lerp_ts(lat0, lat1, prop);
-  tp.lon = lerp_ts(lon0, lon1, prop);
-  tp.elevation = lerp_ts(te0, te1, prop);
-  tp.normal = v3(lerp_ts(n0.x, n1.x, prop), lerp_ts(n0.y, n1.y, prop), lerp_ts(n0.z, n1.z, prop));
-  tp.distance = lerp_ts(dist0, dist1, prop);
-  tp.path_length = lerp_ts(pl0, pl1, prop);
-  return tp;
-}
-
-static __device__ __forceinline__ void store_dense(const DensePlanes& o, size_t p, size_t plane, const TracePointDev& tp) {
-  o.lat[p] = tp.lat;
-  o.lon[p] = tp.lon;
-  o.distance[p] = tp.distance;
-  o.elevation[p] = tp.elevation;
-  o.path_length[p] = tp.path_length;
-  o.normal[p] = tp.normal.x;
-  o.normal[plane + p] = tp.normal.y;
-  o.normal[2 * plane + p] = tp.normal.z;
-}
-static __device__ __forceinline__ void store_dense_miss(const DensePlanes& o, size_t p, size_t plane) {
-  double n = qnan();
-  o.lat[p] = n;
-  o.lon[p] = n;
-  o.distance[p] = n;
-  o.elevation[p] = n;
-  o.path_length[p] = n;
-  o.normal[p] = n;
-  o.normal[plane + p] = n;
-  o.normal[2 * plane + p] = n;
-}
-static __device__ __forceinline__ void store_packed(const PackedHits& o, uint64_t k, const TracePointDev& tp, double alpha) {
-  o.lat[k] = tp.lat;
-  o.lon[k] = tp.lon;
-  o.distance[k] = tp.distance;
-  o.elevation[k] = tp.elevation;
-  o.path_length[k] = tp.path_length;
-  o.normal[3 * k] = tp.normal.x;
-  o.normal[3 * k + 1] = tp.normal.y;
-  o.normal[3 * k + 2] = tp.normal.z;
-  o.color_tag[k] = ATMRT_COLOR_TERRAIN;
-  o.rgba[4 * k] = 0.0;
-  o.rgba[4 * k + 1] = 0.0;
-  o.rgba[4 * k + 2] = 0.0;
-  o.rgba[4 * k + 3] = alpha;
-}
-
-// wave-wide sum of a 64-bit count, result valid in lane 0
-static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
-
-// The DirectionalCalc kind is a compile-time constant in the heavy kernels, so only one of the four
-// calculators (AzEq / FlDs / Spherical / Ellipsoid-Vincenty) is instantiated per kernel variant.
-template <int CALC>
-static __device__ __forceinline__ Earth earth_for(const Frame& f) {
-  Earth e = f.earth;
-  e.calc = CALC;
-  return e;
-}
-#define ATMRT_DISPATCH_CALC(calc, STMT)                  \
-  switch (calc) {                                        \
-    case 0: { constexpr int CALC = 0; STMT; } break;     \
-    case 1: { constexpr int CALC = 1; STMT; } break;     \
-    case 2: { constexpr int CALC = 2; STMT; } break;     \
-    default: { constexpr int CALC = 3; STMT; } break;    \
-  }
 
 // ---------------------------------------------------------------------------------------------
 // set-up: Altitude::abs for the observer and every object (params.rs:23-30, object/mod.rs:166-175)
@@ -171,6 +78,7 @@ __global__ __launch_bounds__(256) void k_terrain_profile(Frame f, const DirCalc*
 // (n(h), n(h - eps), n(h + eps) of Environment::n / dn) run on lanes 0..2 of the quad and are exchanged with
 // shuffles; the cheap remainder of the stage is computed redundantly by all four lanes.  Same operations, same order
 // per value, a third of the dependent chain.
+template <bool CUBIC>
 struct QuadAccel {
   const AtmTable& atm;
   int sub, base;
@@ -178,7 +86,7 @@ struct QuadAccel {
     const double eps = 0.01;
     double h = spherical ? a - radius : a;
     double hh = sub == 1 ? h - eps : sub == 2 ? h + eps : h;
-    double nv = refr_n_hint(atm, hh, hint);
+    double nv = refr_n_hint<CUBIC>(atm, hh, hint);
     double n = __shfl(nv, base, 64), n1 = __shfl(nv, base + 1, 64), n2 = __shfl(nv, base + 2, 64);
     double dn = (n2 - n1) / (2.0 * eps);
     if (spherical) return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
@@ -186,6 +94,7 @@ struct QuadAccel {
   }
 };
 
+template <bool CUBIC>
 __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__ pelev, double* __restrict__ plen,
                                                    int32_t* __restrict__ npath) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,7 +106,7 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   const bool straight = f.p.straight_rays != 0;
   const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
   const double alt = *f.alt;
-  const QuadAccel accel{*f.atm, sub, (int)(threadIdx.x & 63 & ~3)};
+  const QuadAccel<CUBIC> accel{*f.atm, sub, (int)(threadIdx.x & 63 & ~3)};
   Stepper s;
   stepper_init(s, sph, radius, alt, dm_to_radians(frame_row_elev(f, y)));
   size_t base = (size_t)y * f.n_path_cap;
@@ -457,233 +366,6 @@ __global__ __launch_bounds__(256) void k_dense_from_packed(Frame f, const uint64
   store_dense(out, p, plane, tp);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Rectilinear generator: one ray per lane — per-step geodesic point, bilinear terrain gather
-// (4 int16 posts = 8 B), sign test, RK4 step (rectilinear.rs:161-185 driving utils.rs:201-289).
-// MODE 0: opaque, write the dense first hit.  MODE 1: count.  MODE 2: write packed trace points.
-// ---------------------------------------------------------------------------------------------
-// The march only records WHERE the ray crossed the terrain (step index + ray elevation and path
-// length at the two bracketing samples); k_rect_finalize rebuilds the geodesic points, the four
-// finite-difference terrain lookups per sample and the interpolation.  Keeping the hit epilogue out
-// of the march keeps the RK4 loop at ~135 VGPRs without scratch.
-struct RectRec {
-  double* re0; // ray elevation at the older sample   (planar: [n] each)
-  double* pl0; // path length at the older sample
-  double* re1;
-  double* pl1;
-};
-
-// 4 waves per SIMD (<= 128 VGPRs): measured 790 ms (3 waves) -> 702 ms (4) on the headline frame; 5 and 6 spill
-#ifndef ATMRT_MARCH_WAVES
-#define ATMRT_MARCH_WAVES 4
-#endif
-template <int MODE, int CALC>
-__global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
-                                                    const uint64_t* __restrict__ hit_offset, RectRec rec,
-                                                    uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
-                                                    unsigned long long* __restrict__ counters) {
-  const size_t plane = (size_t)f.wl * f.h;
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < plane;
-  unsigned long long steps = 0;
-  if (live) {
-    const Earth e = earth_for<CALC>(f);
-    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
-    const bool sph = e.spherical != 0;
-    const double radius = e.shape_radius;
-    const bool straight = f.p.straight_rays != 0;
-    const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
-    const bool opaque = f.p.terrain_alpha == 1.0;
-    const double alt = *f.alt;
-    double direction, elevation;
-    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
-    DirCalc c;
-    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
-    Stepper s;
-    stepper_init(s, sph, radius, alt, elevation);
-    unsigned count = 0;
-    int first = -1;
-    uint64_t k = MODE == 2 ? hit_offset[p] : 0;
-    // first sample (PathIterator::next at the start state); the reference would panic on an empty stream
-    if (!(0.0 > max_dist || alt < -1000.0)) {
-      double lat, lon;
-      coords_at_dist(e, c, 0.0, lat, lon);
-      double diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
-      double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
-      double sx = 0.0, sh = alt, path_length = 0.0;
-      for (int i = 1;; i++) {
-        RayState st = stepper_next(s, *f.atm, sph, radius, straight, step);
-        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h);
-        sx = st.x;
-        sh = st.h;
-        if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
-        coords_at_dist(e, c, sx, lat, lon);
-        double diff1 = sh - terrain_elev_or_zero(f.tv, lat, lon);
-        steps++;
-        if (diff0 * diff1 < 0.0) { // utils.rs:222
-          if (MODE == 0) {
-            first = i - 1;
-            rec.re0[p] = re0;
-            rec.pl0[p] = pl0;
-            rec.re1[p] = sh;
-            rec.pl1[p] = path_length;
-          } else if (MODE == 2) {
-            list_step[k] = (uint32_t)(i - 1);
-            list_pixel[k] = (uint32_t)p;
-            rec.re0[k] = re0;
-            rec.pl0[k] = pl0;
-            rec.re1[k] = sh;
-            rec.pl1[k] = path_length;
-            k++;
-          }
-          count++;
-          if (opaque) break; // utils.rs:237-239, 283-285
-        }
-        diff0 = diff1;
-        re0 = sh;
-        pl0 = path_length;
-      }
-    }
-    if (MODE != 2) {
-      out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
-      out.elevation_angle[p] = dm_to_degrees(elevation);
-      out.hit_count[p] = count;
-    }
-    if (MODE == 0) hit_step[p] = first;
-  }
-  if (MODE != 2) {
-    steps = wave_sum(steps);
-    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
-  }
-}
-
-// TracePoint of a recorded crossing of pixel (x, y) at step s
-template <int CALC>
-static __device__ __forceinline__ TracePointDev rect_hit(const Frame& f, int x, int y, int s, double re0, double pl0,
-                                                         double re1, double pl1) {
-  const Earth e = earth_for<CALC>(f);
-  double direction, elevation;
-  rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
-  DirCalc c;
-  dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
-  double d0 = f.xs[s], d1 = f.xs[s + 1]; // the stepper's x: 0 + step + ... (same additions as xs)
-  double lat0, lon0, lat1, lon1;
-  coords_at_dist(e, c, d0, lat0, lon0);
-  coords_at_dist(e, c, d1, lat1, lon1);
-  double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
-  double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
-  return terrain_trace_point(f, e, lat0, lon0, te0, re0, d0, pl0, lat1, lon1, te1, re1, d1, pl1);
-}
-
-template <int CALC>
-__global__ __launch_bounds__(256) void k_rect_finalize(Frame f, const int32_t* __restrict__ hit_step, RectRec rec,
-                                                       DensePlanes out) {
-  const size_t plane = (size_t)f.wl * f.h;
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= plane) return;
-  int s = hit_step[p];
-  if (s < 0) {
-    store_dense_miss(out, p, plane);
-    return;
-  }
-  const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
-  store_dense(out, p, plane, rect_hit<CALC>(f, x, y, s, rec.re0[p], rec.pl0[p], rec.re1[p], rec.pl1[p]));
-}
-
-template <int CALC>
-__global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_hits,
-                                                            const uint32_t* __restrict__ list_step,
-                                                            const uint32_t* __restrict__ list_pixel, RectRec rec,
-                                                            PackedHits packed) {
-  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_hits) return;
-  if (f.n_objects && packed.color_tag[k] != ATMRT_COLOR_TERRAIN) return; // object points are already complete
-  uint32_t p = list_pixel[k];
-  int x = (int)(p % (uint32_t)f.wl), y = (int)(p / (uint32_t)f.wl);
-  store_packed(packed, k, rect_hit<CALC>(f, x, y, (int)list_step[k], rec.re0[k], rec.pl0[k], rec.re1[k], rec.pl1[k]),
-               f.p.terrain_alpha);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// General tracer: scenes with objects (and any terrain_alpha).  get_single_pixel in full
-// (utils.rs:201-289): per step the terrain sign change plus the collisions with every object that is
-// close to either sample, stable-sorted by prop; stop after the step if anything opaque was hit.
-// Two passes (count -> exclusive scan -> fill) because the trace-point lists have variable length.
-// ---------------------------------------------------------------------------------------------
-constexpr int STEP_CANDIDATES = 12; // trace points one step may produce here (terrain + 4 per object); more sets the error flag
-constexpr int CLOSE_CAP = 8;        // Rectilinear: objects close to one sample kept per lane; more sets the error flag
-
-struct StepHits {
-  int n;
-  bool finish;
-  int kind[STEP_CANDIDATES]; // -1 terrain, else object index
-  Collision col[STEP_CANDIDATES];
-};
-
-static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int kind, const Collision* c,
-                                                 unsigned long long* counters) {
-  if (sh.n >= STEP_CANDIDATES) {
-    atomicOr(&counters[2], 1ull);
-    return;
-  }
-  int j = sh.n; // step_result.sort_by(prop) is stable: insert behind every element with prop <= new prop
-  while (j > 0 && sh.col[j - 1].prop > prop) {
-    sh.col[j] = sh.col[j - 1];
-    sh.kind[j] = sh.kind[j - 1];
-    j--;
-  }
-  sh.kind[j] = kind;
-  sh.col[j].prop = prop;
-  if (c) {
-    sh.col[j].normal = c->normal;
-    for (int q = 0; q < 4; q++) sh.col[j].color[q] = c->color[q];
-  }
-  sh.n++;
-}
-
-// collisions of one object with the segment, utils.rs:251-278
-static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2,
-                                                   unsigned long long* counters) {
-  Collision col[4];
-  int nc = object_collision(f.objects[idx], f.textures, pos1, pos2, col);
-  for (int q = 0; q < nc; q++) {
-    if (col[q].color[3] == 0.0) continue;
-    step_push(sh, col[q].prop, idx, &col[q], counters);
-    if (col[q].color[3] == 1.0) {
-      sh.finish = true;
-      break;
-    }
-  }
-}
-
-// emit the sorted trace points of one step (fill pass).  Terrain points are finished later by the
-// *_finalize_list kernels (they need find_normal); object points are complete here (utils.rs:261-272).
-static __device__ __forceinline__ void step_emit(const StepHits& sh, const PackedHits& packed, uint32_t* list_step,
-                                                 uint32_t* list_pixel, uint64_t& k, uint32_t pixel, int step_index,
-                                                 double lat0, double lon0, double re0, double d0, double pl0, double lat1,
-                                                 double lon1, double re1, double d1, double pl1) {
-  for (int j = 0; j < sh.n; j++, k++) {
-    list_step[k] = (uint32_t)step_index;
-    list_pixel[k] = pixel;
-    if (sh.kind[j] < 0) {
-      packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
-      continue;
-    }
-    double prop = sh.col[j].prop;
-    packed.lat[k] = lerp_ts(lat0, lat1, prop);
-    packed.lon[k] = lerp_ts(lon0, lon1, prop);
-    packed.distance[k] = lerp_ts(d0, d1, prop);
-    packed.elevation[k] = lerp_ts(re0, re1, prop); // object hits report the RAY elevation (utils.rs:268)
-    packed.path_length[k] = lerp_ts(pl0, pl1, prop);
-    packed.normal[3 * k] = sh.col[j].normal.x;
-    packed.normal[3 * k + 1] = sh.col[j].normal.y;
-    packed.normal[3 * k + 2] = sh.col[j].normal.z;
-    packed.color_tag[k] = ATMRT_COLOR_RGBA;
-    for (int q = 0; q < 4; q++) packed.rgba[4 * k + q] = sh.col[j].color[q];
-  }
-}
-
 // Fast, phase A extras: which objects are close to each terrain sample (TerrainData::from_lat_lon, utils.rs:74-80)
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_close_objects(Frame f, const double* __restrict__ plat,
@@ -776,148 +458,6 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
     if (!FILL) {
       hit_count[p] = count;
       if (px_steps) px_steps[p] = (uint32_t)steps;
-    }
-  }
-  if (!FILL) {
-    steps = wave_sum(steps);
-    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
-  }
-}
-
-// Objects that can EVER be close to a sample of this ray (exact superset of Object::is_close over the whole ray).
-// Spherical model: every sample, lifted to the object's elevation, lies in the great-circle plane span(pos, dir) of the
-// ray's ground track, so |P - P_obj| >= distance of P_obj to that plane.  Azimuthal-equidistant model: the ground track
-// is a straight line of the flat map and z differences vanish, same argument with the line.  A millimetre of slack
-// covers the rounding of the recomputed sample positions.  Other models (ellipsoid geodesics, lat/lon-linear tracks):
-// no pre-filter.  Returns false when the list overflowed (the caller then tests every object, still exact).
-constexpr int CAND_CAP = 24;
-template <int CALC>
-static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n) {
-  n = 0;
-  if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
-  Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
-  for (int j = 0; j < f.n_objects; j++) {
-    const ObjectDev& o = f.objects[j];
-    Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
-    double dperp = dm_fabs(dot(rel, nrm));
-    double reach = dm_sqrt(o.close2) + 1.0e-3;
-    if (dperp <= reach) {
-      if (n >= CAND_CAP) return false;
-      cand[n++] = j;
-    }
-  }
-  return true;
-}
-
-// proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the candidates or over every object
-static __device__ __forceinline__ int close_ids(const Frame& f, const Earth& e, double lat, double lon, bool use_cand,
-                                                const int* cand, int ncand, int* ids, unsigned long long* counters) {
-  const LatLonTrig t = latlon_trig(e, lat, lon);
-  int n = 0;
-  const int total = use_cand ? ncand : f.n_objects;
-  for (int q = 0; q < total; q++) {
-    const int j = use_cand ? cand[q] : q;
-    if (object_is_close(e, f.objects[j], t)) {
-      if (n < CLOSE_CAP) ids[n++] = j;
-      else atomicOr(&counters[2], 2ull);
-    }
-  }
-  return n;
-}
-
-// Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
-// utils.rs:72-88), then the step logic above.
-template <bool FILL, int CALC>
-__global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
-                                                    PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
-                                                    uint32_t* __restrict__ list_pixel,
-                                                    unsigned long long* __restrict__ counters) {
-  const size_t plane = (size_t)f.wl * f.h;
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long steps = 0;
-  if (p < plane) {
-    const Earth e = earth_for<CALC>(f);
-    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
-    const bool sph = e.spherical != 0;
-    const double radius = e.shape_radius;
-    const bool straight = f.p.straight_rays != 0;
-    const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
-    const bool terrain_opaque = f.p.terrain_alpha == 1.0;
-    const double alt = *f.alt;
-    double direction, elevation;
-    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
-    DirCalc c;
-    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
-    Stepper s;
-    stepper_init(s, sph, radius, alt, elevation);
-    unsigned count = 0;
-    uint64_t k = FILL ? hit_offset[p] : 0;
-    if (!(0.0 > max_dist || alt < -1000.0)) {
-      double lat0, lon0;
-      coords_at_dist(e, c, 0.0, lat0, lon0);
-      double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
-      int ids0[CLOSE_CAP], ids1[CLOSE_CAP], cand[CAND_CAP];
-      int ncand = 0;
-      const bool use_cand = ray_candidates<CALC>(f, e, c, cand, ncand);
-      int n0 = close_ids(f, e, lat0, lon0, use_cand, cand, ncand, ids0, counters), n1 = 0;
-      double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
-      double sx = 0.0, sh_ = alt, path_length = 0.0;
-      for (int i = 1;; i++) {
-        RayState st = stepper_next(s, *f.atm, sph, radius, straight, step);
-        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h);
-        sx = st.x;
-        sh_ = st.h;
-        if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
-        double lat1, lon1;
-        coords_at_dist(e, c, sx, lat1, lon1);
-        double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
-        n1 = close_ids(f, e, lat1, lon1, use_cand, cand, ncand, ids1, counters);
-        steps++;
-        StepHits hits;
-        hits.n = 0;
-        hits.finish = false;
-        double diff1 = re0 - te0, diff2 = sh_ - te1;
-        if (diff1 * diff2 < 0.0) {
-          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr, counters);
-          if (terrain_opaque) hits.finish = true;
-        }
-        if (n0 | n1) {
-          Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
-          int ia = 0, ib = 0;
-          while (ia < n0 || ib < n1) {
-            int idx;
-            if (ib >= n1 || (ia < n0 && ids0[ia] <= ids1[ib])) {
-              idx = ids0[ia];
-              if (ib < n1 && ids1[ib] == idx) ib++;
-              ia++;
-            } else {
-              idx = ids1[ib++];
-            }
-            step_object(hits, f, idx, pos1, pos2, counters);
-          }
-        }
-        if (FILL && hits.n) {
-          uint64_t k0 = k;
-          step_emit(hits, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx,
-                    path_length);
-          for (uint64_t q = k0; q < k; q++) { // terrain points: what k_rect_finalize_list needs
-            rec.re0[q] = re0;
-            rec.pl0[q] = pl0;
-            rec.re1[q] = sh_;
-            rec.pl1[q] = path_length;
-          }
-        }
-        count += (unsigned)hits.n;
-        if (hits.finish) break;
-        lat0 = lat1; lon0 = lon1; te0 = te1; re0 = sh_; d0 = sx; pl0 = path_length;
-        n0 = n1;
-        for (int q = 0; q < CLOSE_CAP; q++) ids0[q] = ids1[q];
-      }
-    }
-    if (!FILL) {
-      out.azimuth[p] = dm_to_degrees(direction);
-      out.elevation_angle[p] = dm_to_degrees(elevation);
-      out.hit_count[p] = count;
     }
   }
   if (!FILL) {
@@ -1420,7 +960,10 @@ void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipSt
   (void)hipEventRecord(ev, stream);
   (void)hipStreamWaitEvent(stream2, ev, 0);
   (void)hipEventRecord(timing[2], stream2);
-  hipLaunchKernelGGL(k_fast_paths, dim3(cdiv((size_t)f.h * 4, 64)), dim3(64), 0, stream2, f, ws.pelev, ws.plen, ws.npath);
+  if (f.atm_cubic)
+    hipLaunchKernelGGL((k_fast_paths<true>), dim3(cdiv((size_t)f.h * 4, 64)), dim3(64), 0, stream2, f, ws.pelev, ws.plen, ws.npath);
+  else
+    hipLaunchKernelGGL((k_fast_paths<false>), dim3(cdiv((size_t)f.h * 4, 64)), dim3(64), 0, stream2, f, ws.pelev, ws.plen, ws.npath);
   (void)hipEventRecord(timing[3], stream2);
   (void)hipEventRecord(ev_join, stream2);
   (void)hipEventRecord(timing[0], stream);
@@ -1453,35 +996,6 @@ void launch_fast_finalize(const Frame& f, Workspace& ws, const DensePlanes& out,
                                                         stream, f, ws.colcalc, ws.prof, ws.pelev, ws.plen, ws.hit_step, out));
 }
 
-static RectRec carve_rec(double* base, size_t n) {
-  RectRec r;
-  r.re0 = base;
-  r.pl0 = base + n;
-  r.re1 = base + 2 * n;
-  r.pl1 = base + 3 * n;
-  return r;
-}
-
-void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
-  size_t n = (size_t)f.wl * f.h;
-  RectRec rec = carve_rec(ws.rect_rec, n);
-  if (f.opaque) {
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<0, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
-                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                          (unsigned long long*)ws.counters));
-    (void)hipEventRecord(ev_marched, stream);
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, ws.hit_step, rec, out));
-  } else {
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<1, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
-                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                          (unsigned long long*)ws.counters));
-    (void)hipEventRecord(ev_marched, stream);
-  }
-}
-
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* tmp, uint64_t* out, unsigned long long* total,
                      hipStream_t stream) {
   unsigned nb = cdiv(n, 256 * SCAN_ITEMS);
@@ -1508,69 +1022,10 @@ void launch_close_fill(const Frame& f, Workspace& ws, hipStream_t stream) {
                      ws.coffset, ws.clist);
 }
 
-void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
-  PackedHits none = {};
-  if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
-    size_t n = (size_t)f.wl * f.h;
-    RectRec rec = {};
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, out, (const uint64_t*)nullptr, none, rec, (uint32_t*)nullptr,
-                                                          (uint32_t*)nullptr, (unsigned long long*)ws.counters));
-  } else {
-    hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
-                       ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, out.hit_count, (const uint64_t*)nullptr,
-                       none, (uint32_t*)nullptr, (uint32_t*)nullptr, ws.px_steps, (unsigned long long*)ws.counters);
-  }
-}
-
-void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
-                       hipStream_t stream) {
-  if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
-    size_t n = (size_t)f.wl * f.h;
-    RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, dense, ws.hit_offset, packed, rec, ws.list_step, ws.list_pixel,
-                                                          (unsigned long long*)ws.counters));
-    if (n_hits) {
-      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
-                                                            stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));
-    }
-    hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
-                       dense, 0);
-  } else {
-    hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
-                       ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, dense.hit_count, ws.hit_offset, packed,
-                       ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
-    if (n_hits) {
-      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
-                                                            stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,
-                                                            ws.list_step, ws.list_pixel, packed));
-    }
-    hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
-                       dense, 1);
-  }
-}
-
 void launch_pack_first_hits(const Frame& f, Workspace& ws, const DensePlanes& dense, const PackedHits& packed,
                             hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   hipLaunchKernelGGL(k_pack_first_hits, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.hit_offset, dense, packed);
-}
-
-// terrain_alpha < 1, Rectilinear: second march lists every crossing, then one thread per trace point
-void launch_multi_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
-                       hipStream_t stream) {
-  size_t n = (size_t)f.wl * f.h;
-  RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<2, CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f,
-                                                        dense, ws.hit_step, ws.hit_offset, rec, ws.list_step,
-                                                        ws.list_pixel, (unsigned long long*)ws.counters));
-  if (n_hits) {
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
-                                                          stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));
-  }
-  hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
-                     dense, 0);
 }
 
 void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense,
@@ -1581,8 +1036,41 @@ void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, cons
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                           stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,
                                                           ws.list_step, ws.list_pixel, packed));
-  hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed,
-                     dense, 1);
+  launch_dense_from_packed(f, ws, packed, dense, 1, stream);
+}
+
+void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
+    launch_rect_trace_count(f, ws, out, stream);
+    return;
+  }
+  PackedHits none = {};
+  hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
+                     ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, out.hit_count, (const uint64_t*)nullptr, none,
+                     (uint32_t*)nullptr, (uint32_t*)nullptr, ws.px_steps, (unsigned long long*)ws.counters);
+}
+
+void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                       hipStream_t stream) {
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
+    launch_rect_trace_fill(f, ws, n_hits, dense, packed, stream);
+    return;
+  }
+  hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
+                     ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, dense.hit_count, ws.hit_offset, packed,
+                     ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
+  if (n_hits) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                          stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,
+                                                          ws.list_step, ws.list_pixel, packed));
+  }
+  launch_dense_from_packed(f, ws, packed, dense, 1, stream);
+}
+
+void launch_dense_from_packed(const Frame& f, Workspace& ws, const PackedHits& packed, const DensePlanes& dense, int fast_angles,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(k_dense_from_packed, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.hit_offset, packed, dense,
+                     fast_angles);
 }
 
 void launch_get_elev(const Frame& f, size_t n, const double* lat, const double* lon, double* elev, uint8_t* valid,

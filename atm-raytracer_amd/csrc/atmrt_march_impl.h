@@ -1,0 +1,370 @@
+// atmrt_march_impl.h — Rectilinear generator on gfx950: the per-pixel march (RK4 ray + geodesic point + terrain gather per step),
+// its trace-point epilogue and the general tracer for scenes with objects.  Included by two translation units
+// (atmrt_march_linear.hip, atmrt_march_spline.hip) that instantiate the launchers for atmospheres without / with Spline
+// segments, so the heavy template variants (3 modes x 4 DirectionalCalc kinds x 2) compile in parallel.
+#pragma once
+#include "atmrt_device.h"
+
+namespace atmrt {
+
+// ---------------------------------------------------------------------------------------------
+// Rectilinear generator: one ray per lane — per-step geodesic point, bilinear terrain gather
+// (4 int16 posts = 8 B), sign test, RK4 step (rectilinear.rs:161-185 driving utils.rs:201-289).
+// MODE 0: opaque, write the dense first hit.  MODE 1: count.  MODE 2: write packed trace points.
+// ---------------------------------------------------------------------------------------------
+// The march only records WHERE the ray crossed the terrain (step index + ray elevation and path
+// length at the two bracketing samples); k_rect_finalize rebuilds the geodesic points, the four
+// finite-difference terrain lookups per sample and the interpolation.  Keeping the hit epilogue out
+// of the march keeps the RK4 loop at ~135 VGPRs without scratch.
+
+// 4 waves per SIMD (<= 128 VGPRs): measured 790 ms (3 waves) -> 702 ms (4) on the headline frame; 5 and 6 spill
+#ifndef ATMRT_MARCH_WAVES
+#define ATMRT_MARCH_WAVES 4
+#endif
+template <int MODE, int CALC, bool CUBIC>
+__global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+                                                    const uint64_t* __restrict__ hit_offset, RectRec rec,
+                                                    uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                    unsigned long long* __restrict__ counters) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < plane;
+  unsigned long long steps = 0;
+  if (live) {
+    const Earth e = earth_for<CALC>(f);
+    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+    const bool sph = e.spherical != 0;
+    const double radius = e.shape_radius;
+    const bool straight = f.p.straight_rays != 0;
+    const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+    const bool opaque = f.p.terrain_alpha == 1.0;
+    const double alt = *f.alt;
+    double direction, elevation;
+    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+    DirCalc c;
+    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+    Stepper s;
+    stepper_init(s, sph, radius, alt, elevation);
+    unsigned count = 0;
+    int first = -1;
+    uint64_t k = MODE == 2 ? hit_offset[p] : 0;
+    // first sample (PathIterator::next at the start state); the reference would panic on an empty stream
+    if (!(0.0 > max_dist || alt < -1000.0)) {
+      double lat, lon;
+      coords_at_dist(e, c, 0.0, lat, lon);
+      double diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
+      double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
+      double sx = 0.0, sh = alt, path_length = 0.0;
+      for (int i = 1;; i++) {
+        RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step);
+        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h);
+        sx = st.x;
+        sh = st.h;
+        if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
+        coords_at_dist(e, c, sx, lat, lon);
+        double diff1 = sh - terrain_elev_or_zero(f.tv, lat, lon);
+        steps++;
+        if (diff0 * diff1 < 0.0) { // utils.rs:222
+          if (MODE == 0) {
+            first = i - 1;
+            rec.re0[p] = re0;
+            rec.pl0[p] = pl0;
+            rec.re1[p] = sh;
+            rec.pl1[p] = path_length;
+          } else if (MODE == 2) {
+            list_step[k] = (uint32_t)(i - 1);
+            list_pixel[k] = (uint32_t)p;
+            rec.re0[k] = re0;
+            rec.pl0[k] = pl0;
+            rec.re1[k] = sh;
+            rec.pl1[k] = path_length;
+            k++;
+          }
+          count++;
+          if (opaque) break; // utils.rs:237-239, 283-285
+        }
+        diff0 = diff1;
+        re0 = sh;
+        pl0 = path_length;
+      }
+    }
+    if (MODE != 2) {
+      out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
+      out.elevation_angle[p] = dm_to_degrees(elevation);
+      out.hit_count[p] = count;
+    }
+    if (MODE == 0) hit_step[p] = first;
+  }
+  if (MODE != 2) {
+    steps = wave_sum(steps);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+  }
+}
+
+// TracePoint of a recorded crossing of pixel (x, y) at step s
+template <int CALC>
+static __device__ __forceinline__ TracePointDev rect_hit(const Frame& f, int x, int y, int s, double re0, double pl0,
+                                                         double re1, double pl1) {
+  const Earth e = earth_for<CALC>(f);
+  double direction, elevation;
+  rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+  DirCalc c;
+  dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+  double d0 = f.xs[s], d1 = f.xs[s + 1]; // the stepper's x: 0 + step + ... (same additions as xs)
+  double lat0, lon0, lat1, lon1;
+  coords_at_dist(e, c, d0, lat0, lon0);
+  coords_at_dist(e, c, d1, lat1, lon1);
+  double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
+  double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
+  return terrain_trace_point(f, e, lat0, lon0, te0, re0, d0, pl0, lat1, lon1, te1, re1, d1, pl1);
+}
+
+template <int CALC>
+__global__ __launch_bounds__(256) void k_rect_finalize(Frame f, const int32_t* __restrict__ hit_step, RectRec rec,
+                                                       DensePlanes out) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  int s = hit_step[p];
+  if (s < 0) {
+    store_dense_miss(out, p, plane);
+    return;
+  }
+  const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+  store_dense(out, p, plane, rect_hit<CALC>(f, x, y, s, rec.re0[p], rec.pl0[p], rec.re1[p], rec.pl1[p]));
+}
+
+template <int CALC>
+__global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_hits,
+                                                            const uint32_t* __restrict__ list_step,
+                                                            const uint32_t* __restrict__ list_pixel, RectRec rec,
+                                                            PackedHits packed) {
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_hits) return;
+  if (f.n_objects && packed.color_tag[k] != ATMRT_COLOR_TERRAIN) return; // object points are already complete
+  uint32_t p = list_pixel[k];
+  int x = (int)(p % (uint32_t)f.wl), y = (int)(p / (uint32_t)f.wl);
+  store_packed(packed, k, rect_hit<CALC>(f, x, y, (int)list_step[k], rec.re0[k], rec.pl0[k], rec.re1[k], rec.pl1[k]),
+               f.p.terrain_alpha);
+}
+
+
+// Objects that can EVER be close to a sample of this ray (exact superset of Object::is_close over the whole ray).
+// Spherical model: every sample, lifted to the object's elevation, lies in the great-circle plane span(pos, dir) of the
+// ray's ground track, so |P - P_obj| >= distance of P_obj to that plane.  Azimuthal-equidistant model: the ground track
+// is a straight line of the flat map and z differences vanish, same argument with the line.  A millimetre of slack
+// covers the rounding of the recomputed sample positions.  Other models (ellipsoid geodesics, lat/lon-linear tracks):
+// no pre-filter.  Returns false when the list overflowed (the caller then tests every object, still exact).
+constexpr int CAND_CAP = 24;
+template <int CALC>
+static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n) {
+  n = 0;
+  if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
+  Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
+  for (int j = 0; j < f.n_objects; j++) {
+    const ObjectDev& o = f.objects[j];
+    Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
+    double dperp = dm_fabs(dot(rel, nrm));
+    double reach = dm_sqrt(o.close2) + 1.0e-3;
+    if (dperp <= reach) {
+      if (n >= CAND_CAP) return false;
+      cand[n++] = j;
+    }
+  }
+  return true;
+}
+
+// proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the candidates or over every object
+static __device__ __forceinline__ int close_ids(const Frame& f, const Earth& e, double lat, double lon, bool use_cand,
+                                                const int* cand, int ncand, int* ids, unsigned long long* counters) {
+  const LatLonTrig t = latlon_trig(e, lat, lon);
+  int n = 0;
+  const int total = use_cand ? ncand : f.n_objects;
+  for (int q = 0; q < total; q++) {
+    const int j = use_cand ? cand[q] : q;
+    if (object_is_close(e, f.objects[j], t)) {
+      if (n < CLOSE_CAP) ids[n++] = j;
+      else atomicOr(&counters[2], 2ull);
+    }
+  }
+  return n;
+}
+
+// Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
+// utils.rs:72-88), then the step logic above.
+template <bool FILL, int CALC, bool CUBIC>
+__global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
+                                                    PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
+                                                    uint32_t* __restrict__ list_pixel,
+                                                    unsigned long long* __restrict__ counters) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long steps = 0;
+  if (p < plane) {
+    const Earth e = earth_for<CALC>(f);
+    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+    const bool sph = e.spherical != 0;
+    const double radius = e.shape_radius;
+    const bool straight = f.p.straight_rays != 0;
+    const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+    const bool terrain_opaque = f.p.terrain_alpha == 1.0;
+    const double alt = *f.alt;
+    double direction, elevation;
+    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+    DirCalc c;
+    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+    Stepper s;
+    stepper_init(s, sph, radius, alt, elevation);
+    unsigned count = 0;
+    uint64_t k = FILL ? hit_offset[p] : 0;
+    if (!(0.0 > max_dist || alt < -1000.0)) {
+      double lat0, lon0;
+      coords_at_dist(e, c, 0.0, lat0, lon0);
+      double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
+      int ids0[CLOSE_CAP], ids1[CLOSE_CAP], cand[CAND_CAP];
+      int ncand = 0;
+      const bool use_cand = ray_candidates<CALC>(f, e, c, cand, ncand);
+      int n0 = close_ids(f, e, lat0, lon0, use_cand, cand, ncand, ids0, counters), n1 = 0;
+      double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
+      double sx = 0.0, sh_ = alt, path_length = 0.0;
+      for (int i = 1;; i++) {
+        RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step);
+        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h);
+        sx = st.x;
+        sh_ = st.h;
+        if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
+        double lat1, lon1;
+        coords_at_dist(e, c, sx, lat1, lon1);
+        double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
+        n1 = close_ids(f, e, lat1, lon1, use_cand, cand, ncand, ids1, counters);
+        steps++;
+        StepHits hits;
+        hits.n = 0;
+        hits.finish = false;
+        double diff1 = re0 - te0, diff2 = sh_ - te1;
+        if (diff1 * diff2 < 0.0) {
+          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr, counters);
+          if (terrain_opaque) hits.finish = true;
+        }
+        if (n0 | n1) {
+          Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
+          int ia = 0, ib = 0;
+          while (ia < n0 || ib < n1) {
+            int idx;
+            if (ib >= n1 || (ia < n0 && ids0[ia] <= ids1[ib])) {
+              idx = ids0[ia];
+              if (ib < n1 && ids1[ib] == idx) ib++;
+              ia++;
+            } else {
+              idx = ids1[ib++];
+            }
+            step_object(hits, f, idx, pos1, pos2, counters);
+          }
+        }
+        if (FILL && hits.n) {
+          uint64_t k0 = k;
+          step_emit(hits, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx,
+                    path_length);
+          for (uint64_t q = k0; q < k; q++) { // terrain points: what k_rect_finalize_list needs
+            rec.re0[q] = re0;
+            rec.pl0[q] = pl0;
+            rec.re1[q] = sh_;
+            rec.pl1[q] = path_length;
+          }
+        }
+        count += (unsigned)hits.n;
+        if (hits.finish) break;
+        lat0 = lat1; lon0 = lon1; te0 = te1; re0 = sh_; d0 = sx; pl0 = path_length;
+        n0 = n1;
+        for (int q = 0; q < CLOSE_CAP; q++) ids0[q] = ids1[q];
+      }
+    }
+    if (!FILL) {
+      out.azimuth[p] = dm_to_degrees(direction);
+      out.elevation_angle[p] = dm_to_degrees(elevation);
+      out.hit_count[p] = count;
+    }
+  }
+  if (!FILL) {
+    steps = wave_sum(steps);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+
+template <bool CUBIC>
+void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
+  size_t n = (size_t)f.wl * f.h;
+  RectRec rec = carve_rec(ws.rect_rec, n);
+  if (f.opaque) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<0, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
+                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                          (unsigned long long*)ws.counters));
+    (void)hipEventRecord(ev_marched, stream);
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, ws.hit_step, rec, out));
+  } else {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<1, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
+                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                          (unsigned long long*)ws.counters));
+    (void)hipEventRecord(ev_marched, stream);
+  }
+}
+
+// terrain_alpha < 1, Rectilinear: second march lists every crossing, then one thread per trace point
+template <bool CUBIC>
+void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                         hipStream_t stream) {
+  size_t n = (size_t)f.wl * f.h;
+  RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<2, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f,
+                                                        dense, ws.hit_step, ws.hit_offset, rec, ws.list_step,
+                                                        ws.list_pixel, (unsigned long long*)ws.counters));
+  if (n_hits) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                          stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));
+  }
+  launch_dense_from_packed(f, ws, packed, dense, 0, stream);
+}
+
+
+template <bool CUBIC>
+void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  PackedHits none = {};
+  size_t n = (size_t)f.wl * f.h;
+  RectRec rec = {};
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
+                                                        (const uint64_t*)nullptr, none, rec, (uint32_t*)nullptr,
+                                                        (uint32_t*)nullptr, (unsigned long long*)ws.counters));
+}
+
+template <bool CUBIC>
+void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
+                              hipStream_t stream) {
+  size_t n = (size_t)f.wl * f.h;
+  RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, dense, ws.hit_offset,
+                                                        packed, rec, ws.list_step, ws.list_pixel,
+                                                        (unsigned long long*)ws.counters));
+  if (n_hits) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
+                                                          stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));
+  }
+  launch_dense_from_packed(f, ws, packed, dense, 0, stream);
+}
+
+// explicit instantiation of every launcher for one value of CUBIC
+#define ATMRT_INSTANTIATE_MARCH(CUBIC)                                                                                        \
+  template void launch_rect_march_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t, hipEvent_t);            \
+  template void launch_multi_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,         \
+                                           hipStream_t);                                                                      \
+  template void launch_rect_trace_count_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);                  \
+  template void launch_rect_trace_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,    \
+                                                hipStream_t);
+
+} // namespace atmrt

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ATMRT_ABI_VERSION 1
+#define ATMRT_ABI_VERSION 2
 
 typedef enum atmrt_status {
   ATMRT_OK = 0,
@@ -34,7 +34,7 @@ typedef enum atmrt_status {
   ATMRT_ERR_IO = -4,               /* terrain directory or file unreadable (terrain/mod.rs:70-71) */
   ATMRT_ERR_FORMAT = -5,           /* a file in the terrain directory is not a DTED tile (terrain/mod.rs:113-118) */
   ATMRT_ERR_STATE = -6,            /* call order violated (e.g. generate before set_params) */
-  ATMRT_ERR_UNSUPPORTED = -7       /* schema element outside the hot-path scope (e.g. Spline temperature) */
+  ATMRT_ERR_UNSUPPORTED = -7       /* a fixed capacity of the device path was exceeded (message says which) */
 } atmrt_status;
 
 /* EarthModel, src/utils/earth_model/mod.rs:19-28 (same order as the Rust enum). */
@@ -100,19 +100,36 @@ typedef struct atmrt_params {
   uint16_t col_end;            /*   0,0 means the whole width.  Multi-GPU: one context per rank. */
 } atmrt_params_t;
 
-/* AtmosphereDef of crate atm-refraction 0.6 (schema: reference README.md:283-323).  Only `Linear`
- * temperature functions are inside the hot-path scope this round; `Spline` returns
- * ATMRT_ERR_UNSUPPORTED from the host-side parser. */
-#define ATMRT_MAX_ATM_LAYERS 16
+/* AtmosphereDef of crate atm-refraction 0.6 (schema: reference README.md:283-323): a pressure fixed point, a list of
+ * temperature functions (the first from -inf, every next one from its `altitude` upwards), each either `Linear{gradient}`
+ * or `Spline{boundary_condition, points}`, and — when every function is Linear — a temperature fixed point. */
+#define ATMRT_MAX_ATM_FUNCTIONS 8
+#define ATMRT_MAX_SPLINE_POINTS 32
+typedef enum atmrt_temp_function_kind { ATMRT_TEMP_LINEAR = 0, ATMRT_TEMP_SPLINE = 1 } atmrt_temp_function_kind;
+typedef enum atmrt_spline_boundary {
+  ATMRT_SPLINE_NATURAL = 0,            /* second derivative 0 at both ends */
+  ATMRT_SPLINE_DERIVATIVES = 1,        /* first derivatives bc[0], bc[1] at the ends */
+  ATMRT_SPLINE_SECOND_DERIVATIVES = 2  /* second derivatives bc[0], bc[1] at the ends */
+} atmrt_spline_boundary;
+typedef struct atmrt_temp_function {
+  int32_t kind;      /* atmrt_temp_function_kind */
+  int32_t boundary;  /* enum atmrt_spline_boundary; Spline only */
+  double altitude;   /* applies for h >= altitude; ignored for the first function */
+  double gradient;   /* Linear: dT/dh [K/m] */
+  double bc[2];      /* Spline boundary values */
+  int32_t n_points;  /* Spline: 2..ATMRT_MAX_SPLINE_POINTS, strictly increasing altitudes */
+  int32_t _pad;
+  double point_altitude[ATMRT_MAX_SPLINE_POINTS];
+  double point_temperature[ATMRT_MAX_SPLINE_POINTS];
+} atmrt_temp_function_t;
 typedef struct atmrt_atmosphere {
   double pressure_altitude;          /* pressure fixed point */
   double pressure;                   /* [Pa] */
-  double temperature_altitude;       /* temperature_fixed_point */
+  double temperature_altitude;       /* temperature_fixed_point (used only when has_temperature_fixed_point) */
   double temperature;                /* [K] */
-  int32_t n_layers;                  /* >= 1: layer 0 = first_temperature_function (from -inf) */
-  int32_t _pad;
-  double layer_altitude[ATMRT_MAX_ATM_LAYERS]; /* layer k (k>=1) applies at altitude >= layer_altitude[k]; [0] unused */
-  double layer_gradient[ATMRT_MAX_ATM_LAYERS]; /* dT/dh [K/m] */
+  int32_t has_temperature_fixed_point;
+  int32_t n_functions;               /* 1..ATMRT_MAX_ATM_FUNCTIONS */
+  atmrt_temp_function_t functions[ATMRT_MAX_ATM_FUNCTIONS];
 } atmrt_atmosphere_t;
 
 /* Scene objects, src/object/mod.rs:19-75,119-131 after ConfShape::into_shape. */

@@ -4,16 +4,21 @@
  * UNPINNED): `Atmosphere::from_def` (params.rs:514), `atmosphere.temperature/pressure`
  * (atm_printer.rs:37-46), `Environment::n` (renderer/mod.rs:425) and the dn/dh the ray ODE needs.
  * Published models used (choices recorded in DESIGN.md):
- *   - temperature: piecewise-linear lapse-rate layers, schema of README.md:283-323;
- *     `AtmosphereDef::us_76` = U.S. Standard Atmosphere 1976 layers 0-86 km (NOAA-S/T 76-1562);
- *   - pressure: hydrostatic equilibrium of an ideal gas, closed form per layer (same document,
- *     eq. 33a/33b) with g0 = 9.80665 m/s2, M = 0.0289644 kg/mol, R* = 8.31432 J/(mol K);
+ *   - temperature: the functions of the YAML schema (README.md:283-323): `Linear{gradient}` and `Spline` (interpolating
+ *     cubic spline through the points with Natural / Derivatives / SecondDerivatives end conditions, continued linearly
+ *     with its end slope outside its knots); Linear functions take their level from the temperature fixed point or from
+ *     continuity with a neighbouring function; `AtmosphereDef::us_76` = U.S. Standard Atmosphere 1976 layers 0-86 km;
+ *   - pressure: hydrostatic equilibrium of an ideal gas, p = p_b exp(-(g0 M/R) Int dh/T): closed form on Linear
+ *     functions (NOAA-S/T 76-1562 eq. 33a/33b), 5-point Gauss-Legendre quadrature per spline interval;
+ *     g0 = 9.80665 m/s2, M = 0.0289644 kg/mol, R* = 8.31432 J/(mol K);
  *   - refractive index: Ciddor (Appl. Opt. 35, 1566, 1996) as documented by NIST's Engineering
  *     Metrology Toolbox, dry air (the YAML schema has no humidity), x_CO2 = 450 umol/mol;
  *   - dn/dh: central difference with eps = 0.01 m.
  */
 #include "oracle.h"
 #include "oracle_math.h"
+
+#include <string.h>
 
 #define G0 9.80665
 #define M_AIR 0.0289644
@@ -23,15 +28,17 @@ void oracle_atmosphere_us76(atmrt_atmosphere_t* a) {
   static const double alt[7] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0};
   static const double lapse[7] = {-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002};
   int k;
+  memset(a, 0, sizeof *a);
   a->pressure_altitude = 0.0;
   a->pressure = 101325.0;
   a->temperature_altitude = 0.0;
   a->temperature = 288.15;
-  a->n_layers = 7;
-  a->_pad = 0;
-  for (k = 0; k < ATMRT_MAX_ATM_LAYERS; k++) {
-    a->layer_altitude[k] = k < 7 ? alt[k] : 0.0;
-    a->layer_gradient[k] = k < 7 ? lapse[k] : 0.0;
+  a->has_temperature_fixed_point = 1;
+  a->n_functions = 7;
+  for (k = 0; k < 7; k++) {
+    a->functions[k].kind = ATMRT_TEMP_LINEAR;
+    a->functions[k].altitude = alt[k];
+    a->functions[k].gradient = lapse[k];
   }
 }
 
@@ -42,8 +49,31 @@ static int layer_of(const oracle_env_atm* a, double h) {
   return 0;
 }
 
-/* p(h)/pb of layer k */
+static double cubic_temperature(const oracle_env_atm* a, int k, double dh) {
+  return a->tb[k] + dh * (a->lapse[k] + dh * (a->c2[k] + dh * a->c3[k]));
+}
+
+static double seg_temperature(const oracle_env_atm* a, int k, double h) {
+  if (a->cubic[k]) return cubic_temperature(a, k, h - a->hb[k]);
+  return a->tb[k] + a->lapse[k] * (h - a->hb[k]);
+}
+
+/* Int_{hb}^{hb+dh} dh'/T(h'): 5-point Gauss-Legendre */
+static double inv_t_integral(const oracle_env_atm* a, int k, double dh) {
+  const double x1 = 0.5384693101056831, x2 = 0.9061798459386640;
+  const double w0 = 0.5688888888888889, w1 = 0.4786286704993665, w2 = 0.2369268850561891;
+  double half = 0.5 * dh;
+  double s = w0 / cubic_temperature(a, k, half);
+  s += w1 / cubic_temperature(a, k, half - half * x1);
+  s += w1 / cubic_temperature(a, k, half + half * x1);
+  s += w2 / cubic_temperature(a, k, half - half * x2);
+  s += w2 / cubic_temperature(a, k, half + half * x2);
+  return half * s;
+}
+
+/* p(h)/pb of segment k */
 static double pressure_ratio(const oracle_env_atm* a, int k, double h) {
+  if (a->cubic[k]) return om_exp(a->expo[k] * inv_t_integral(a, k, h - a->hb[k]));
   if (a->lapse[k] != 0.0) {
     double t = a->tb[k] + a->lapse[k] * (h - a->hb[k]);
     return om_pow(t / a->tb[k], a->expo[k]);
@@ -51,40 +81,158 @@ static double pressure_ratio(const oracle_env_atm* a, int k, double h) {
   return om_exp(a->expo[k] * (h - a->hb[k]));
 }
 
+/* interpolating cubic spline: second derivatives m[] by the Thomas algorithm */
+static void spline_second_derivatives(const atmrt_temp_function_t* fn, double* m) {
+  const int np = fn->n_points;
+  const double* x = fn->point_altitude;
+  const double* y = fn->point_temperature;
+  double cp[ATMRT_MAX_SPLINE_POINTS], dp[ATMRT_MAX_SPLINE_POINTS];
+  double b0, c0, d0, an, bn, dn;
+  int i;
+  if (fn->boundary == ATMRT_SPLINE_DERIVATIVES) {
+    double h0 = x[1] - x[0], hn = x[np - 1] - x[np - 2];
+    b0 = 2.0 * h0; c0 = h0; d0 = 6.0 * ((y[1] - y[0]) / h0 - fn->bc[0]);
+    an = hn; bn = 2.0 * hn; dn = 6.0 * (fn->bc[1] - (y[np - 1] - y[np - 2]) / hn);
+  } else {
+    b0 = 1.0; c0 = 0.0; d0 = fn->boundary == ATMRT_SPLINE_SECOND_DERIVATIVES ? fn->bc[0] : 0.0;
+    an = 0.0; bn = 1.0; dn = fn->boundary == ATMRT_SPLINE_SECOND_DERIVATIVES ? fn->bc[1] : 0.0;
+  }
+  cp[0] = c0 / b0;
+  dp[0] = d0 / b0;
+  for (i = 1; i < np; i++) {
+    double ai, bi, ci, di, den;
+    if (i < np - 1) {
+      double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+      ai = hl; bi = 2.0 * (hl + hr); ci = hr;
+      di = 6.0 * ((y[i + 1] - y[i]) / hr - (y[i] - y[i - 1]) / hl);
+    } else {
+      ai = an; bi = bn; ci = 0.0; di = dn;
+    }
+    den = bi - ai * cp[i - 1];
+    cp[i] = ci / den;
+    dp[i] = (di - ai * dp[i - 1]) / den;
+  }
+  m[np - 1] = dp[np - 1];
+  for (i = np - 2; i >= 0; i--) m[i] = dp[i] - cp[i] * m[i + 1];
+}
+
 int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_env_atm* out) {
   const double gmr = G0 * M_AIR / R_GAS;
-  int n = def->n_layers, k, jt, jp;
-  if (n < 1 || n > ATMRT_MAX_ATM_LAYERS) return -1;
+  const int nf = def->n_functions;
+  int n = 0, j, k, pass, any = 0, jp;
+  int first_seg[ATMRT_MAX_ATM_FUNCTIONS + 1], anchored[ATMRT_MAX_ATM_FUNCTIONS];
+  if (nf < 1 || nf > ATMRT_MAX_ATM_FUNCTIONS) return -1;
+  memset(out, 0, sizeof *out);
+  for (j = 2; j < nf; j++)
+    if (!(def->functions[j].altitude > def->functions[j - 1].altitude)) return -2;
+  for (j = 0; j < nf; j++) {
+    const atmrt_temp_function_t* fn = &def->functions[j];
+    const int has_lo = j > 0, has_hi = j + 1 < nf;
+    const double lo = has_lo ? fn->altitude : 0.0, hi = has_hi ? def->functions[j + 1].altitude : 0.0;
+    first_seg[j] = n;
+    anchored[j] = 0;
+    if (fn->kind == ATMRT_TEMP_LINEAR) {
+      if (n >= ORACLE_MAX_SEGMENTS) return -5;
+      out->from[n] = lo;
+      out->lapse[n] = fn->gradient;
+      n++;
+      continue;
+    }
+    if (fn->kind != ATMRT_TEMP_SPLINE) return -1;
+    {
+      const int np = fn->n_points;
+      const double* x = fn->point_altitude;
+      const double* y = fn->point_temperature;
+      double m[ATMRT_MAX_SPLINE_POINTS];
+      int i;
+      if (np < 2 || np > ATMRT_MAX_SPLINE_POINTS) return -4;
+      for (i = 1; i < np; i++)
+        if (!(x[i] > x[i - 1])) return -4;
+      spline_second_derivatives(fn, m);
+      if (!has_lo || lo < x[0]) { /* linear continuation below the first knot, slope S'(x0) */
+        double hh = x[1] - x[0];
+        if (n >= ORACLE_MAX_SEGMENTS) return -5;
+        out->from[n] = lo;
+        out->hb[n] = x[0];
+        out->tb[n] = y[0];
+        out->lapse[n] = (y[1] - y[0]) / hh - hh * (2.0 * m[0] + m[1]) / 6.0;
+        n++;
+      }
+      for (i = 0; i + 1 < np; i++) {
+        double hh;
+        if (has_hi && x[i] >= hi) break;
+        if (has_lo && x[i + 1] <= lo) continue;
+        if (n >= ORACLE_MAX_SEGMENTS) return -5;
+        hh = x[i + 1] - x[i];
+        out->from[n] = (has_lo && lo > x[i]) ? lo : x[i];
+        out->hb[n] = x[i];
+        out->tb[n] = y[i];
+        out->lapse[n] = (y[i + 1] - y[i]) / hh - hh * (2.0 * m[i] + m[i + 1]) / 6.0;
+        out->c2[n] = m[i] / 2.0;
+        out->c3[n] = (m[i + 1] - m[i]) / (6.0 * hh);
+        out->cubic[n] = 1;
+        n++;
+      }
+      if (!has_hi || hi > x[np - 1]) { /* linear continuation above the last knot, slope S'(x_last) */
+        double hh = x[np - 1] - x[np - 2];
+        if (n >= ORACLE_MAX_SEGMENTS) return -5;
+        out->from[n] = x[np - 1];
+        out->hb[n] = x[np - 1];
+        out->tb[n] = y[np - 1];
+        out->lapse[n] = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0;
+        n++;
+      }
+      anchored[j] = 1;
+    }
+  }
+  first_seg[nf] = n;
   out->n = n;
-  for (k = 0; k < n; k++) {
-    out->lapse[k] = def->layer_gradient[k];
-    out->from[k] = k == 0 ? 0.0 : def->layer_altitude[k];
-    if (k >= 2 && !(out->from[k] > out->from[k - 1])) return -1;
+  out->from[0] = 0.0;
+  /* absolute temperature of the Linear functions */
+  if (def->has_temperature_fixed_point) {
+    int jt = 0;
+    for (j = nf - 1; j >= 1; j--)
+      if (def->temperature_altitude >= def->functions[j].altitude) { jt = j; break; }
+    if (def->functions[jt].kind == ATMRT_TEMP_LINEAR && !anchored[jt]) {
+      k = first_seg[jt];
+      out->hb[k] = jt == 0 ? def->temperature_altitude : out->from[k];
+      out->tb[k] = def->temperature - out->lapse[k] * (def->temperature_altitude - out->hb[k]);
+      anchored[jt] = 1;
+    }
   }
-  /* temperature: chain outwards from the layer that holds the fixed point */
-  jt = 0;
-  for (k = n - 1; k >= 1; k--)
-    if (def->temperature_altitude >= out->from[k]) { jt = k; break; }
-  out->hb[jt] = jt == 0 ? def->temperature_altitude : out->from[jt];
-  out->tb[jt] = def->temperature - out->lapse[jt] * (def->temperature_altitude - out->hb[jt]);
-  for (k = jt + 1; k < n; k++) {
-    out->hb[k] = out->from[k];
-    out->tb[k] = out->tb[k - 1] + out->lapse[k - 1] * (out->from[k] - out->hb[k - 1]);
-  }
-  for (k = jt - 1; k >= 0; k--) {
-    /* layer k ends at from[k+1], where layer k+1 has temperature tb[k+1] */
-    out->hb[k] = k == 0 ? out->from[1] : out->from[k];
-    out->tb[k] = out->tb[k + 1] - out->lapse[k] * (out->from[k + 1] - out->hb[k]);
+  for (j = 0; j < nf; j++) any = any || anchored[j];
+  if (!any) return -3;
+  for (pass = 0; pass < nf; pass++) {
+    for (j = 0; j < nf; j++) {
+      if (anchored[j]) continue;
+      k = first_seg[j];
+      if (j > 0 && anchored[j - 1]) {
+        int kl = first_seg[j] - 1;
+        out->hb[k] = out->from[k];
+        out->tb[k] = seg_temperature(out, kl, out->from[k]);
+        anchored[j] = 1;
+      } else if (j + 1 < nf && anchored[j + 1]) {
+        int ku = first_seg[j + 1];
+        double top = def->functions[j + 1].altitude;
+        out->hb[k] = j == 0 ? top : out->from[k];
+        out->tb[k] = seg_temperature(out, ku, top) - out->lapse[k] * (top - out->hb[k]);
+        anchored[j] = 1;
+      }
+    }
   }
   for (k = 0; k < n; k++)
-    out->expo[k] = out->lapse[k] != 0.0 ? -gmr / out->lapse[k] : -gmr / out->tb[k];
-  /* pressure: same chaining from the pressure fixed point */
-  jp = 0;
-  for (k = n - 1; k >= 1; k--)
-    if (def->pressure_altitude >= out->from[k]) { jp = k; break; }
+    out->expo[k] = out->cubic[k] ? -gmr : (out->lapse[k] != 0.0 ? -gmr / out->lapse[k] : -gmr / out->tb[k]);
+  /* pressure: chain outwards from the pressure fixed point */
+  jp = layer_of(out, def->pressure_altitude);
   out->pb[jp] = def->pressure / pressure_ratio(out, jp, def->pressure_altitude);
-  for (k = jp + 1; k < n; k++) out->pb[k] = out->pb[k - 1] * pressure_ratio(out, k - 1, out->from[k]);
-  for (k = jp - 1; k >= 0; k--) out->pb[k] = out->pb[k + 1] / pressure_ratio(out, k, out->from[k + 1]);
+  for (k = jp + 1; k < n; k++) {
+    double pk = out->pb[k - 1] * pressure_ratio(out, k - 1, out->from[k]);
+    out->pb[k] = pk / pressure_ratio(out, k, out->from[k]);
+  }
+  for (k = jp - 1; k >= 0; k--) {
+    double pk = out->pb[k + 1] * pressure_ratio(out, k + 1, out->from[k + 1]);
+    out->pb[k] = pk / pressure_ratio(out, k, out->from[k + 1]);
+  }
   {
     /* Ciddor 1996, dry air: (n - 1) = (rho_a / rho_axs) * r_axs,  rho = p*Ma/(Z*R*T) */
     const double k0 = 238.0185, k1 = 5792105.0, k2 = 57.362, k3 = 167917.0;
@@ -100,10 +248,7 @@ int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_
   return 0;
 }
 
-double oracle_atm_temperature(const oracle_env_atm* a, double h) {
-  int k = layer_of(a, h);
-  return a->tb[k] + a->lapse[k] * (h - a->hb[k]);
-}
+double oracle_atm_temperature(const oracle_env_atm* a, double h) { return seg_temperature(a, layer_of(a, h), h); }
 
 double oracle_atm_pressure(const oracle_env_atm* a, double h) {
   int k = layer_of(a, h);
@@ -114,7 +259,7 @@ double oracle_atm_pressure(const oracle_env_atm* a, double h) {
 double oracle_n(const oracle_env_atm* a, double h) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   int k = layer_of(a, h);
-  double temp = a->tb[k] + a->lapse[k] * (h - a->hb[k]);
+  double temp = seg_temperature(a, k, h);
   double p = a->pb[k] * pressure_ratio(a, k, h);
   double t = temp - 273.15;
   double pt = p / temp;

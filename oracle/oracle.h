@@ -24,14 +24,18 @@ extern "C" {
 typedef struct { double x, y, z; } ovec3;
 
 /* ---- atmosphere + refractive index (crate atm-refraction, absent) ------------------------- */
-typedef struct {
+#define ORACLE_MAX_SEGMENTS 64
+typedef struct { /* the atmosphere compiled into segments: T(h) = tb + c1 dh + c2 dh^2 + c3 dh^3, dh = h - hb */
   int n;
-  double hb[ATMRT_MAX_ATM_LAYERS]; /* reference altitude of the layer */
-  double tb[ATMRT_MAX_ATM_LAYERS]; /* temperature at hb */
-  double pb[ATMRT_MAX_ATM_LAYERS]; /* pressure at hb */
-  double lapse[ATMRT_MAX_ATM_LAYERS];
-  double from[ATMRT_MAX_ATM_LAYERS]; /* layer k>=1 applies for h >= from[k] */
-  double expo[ATMRT_MAX_ATM_LAYERS]; /* lapse != 0: -g0*M/(R*lapse);  lapse == 0: -g0*M/(R*tb) */
+  double hb[ORACLE_MAX_SEGMENTS];    /* reference altitude of the segment */
+  double tb[ORACLE_MAX_SEGMENTS];    /* temperature at hb */
+  double pb[ORACLE_MAX_SEGMENTS];    /* pressure at hb */
+  double lapse[ORACLE_MAX_SEGMENTS]; /* c1 */
+  double from[ORACLE_MAX_SEGMENTS];  /* segment k>=1 applies for h >= from[k] */
+  double expo[ORACLE_MAX_SEGMENTS];  /* linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R */
+  double c2[ORACLE_MAX_SEGMENTS];
+  double c3[ORACLE_MAX_SEGMENTS];
+  int cubic[ORACLE_MAX_SEGMENTS];    /* 1: a knot interval of a Spline temperature function */
   double k_refr;                     /* (n-1) = k_refr * (p/T) / Z */
 } oracle_env_atm;
 

@@ -22,7 +22,8 @@ class Vec3(C.Structure):
 
 
 class EnvAtm(C.Structure):
-    _fields_ = [("n", C.c_int)] + [(k, C.c_double * _abi.MAX_ATM_LAYERS) for k in ("hb", "tb", "pb", "lapse", "from_", "expo")] + [("k_refr", C.c_double)]
+    _fields_ = [("n", C.c_int)] + [(k, C.c_double * 64) for k in ("hb", "tb", "pb", "lapse", "from_", "expo", "c2", "c3")] + \
+        [("cubic", C.c_int * 64), ("k_refr", C.c_double)]
 
 
 class DirCalc(C.Structure):

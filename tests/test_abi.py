@@ -42,7 +42,8 @@ def test_defaults_match_the_reference(lib):
     assert (p.position.altitude_kind, p.position.altitude) == (_abi.ALT_RELATIVE, 1.0)  # :42-44
     a = _abi.Atmosphere()
     lib.atmrt_atmosphere_us76(C.byref(a))
-    assert a.n_layers == 7 and a.pressure == 101325.0 and a.temperature == 288.15 and a.layer_gradient[0] == -0.0065
+    assert a.n_functions == 7 and a.pressure == 101325.0 and a.temperature == 288.15 and a.functions[0].gradient == -0.0065
+    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 2
 
 
 def test_no_cpu_fallback(lib):

@@ -68,7 +68,7 @@ def test_parameter_validation(gpu_ctx):
     p.earth.kind = 99
     assert gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(p)) == _abi.ERR_INVALID_ARGUMENT
     a = config.us76()
-    a.n_layers = 0
+    a.n_functions = 0
     assert gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(a)) == _abi.ERR_INVALID_ARGUMENT
     o = _abi.Object()
     o.kind = _abi.OBJ_BILLBOARD  # no texture
@@ -181,3 +181,14 @@ def test_atmosphere_harness_and_custom_layers(gpu_ctx, oracle_det):
     # restore the default atmosphere for the tests that follow
     us = config.us76()
     gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(us)))
+
+
+def test_maximum_width(gpu_ctx, oracle_det):
+    """The widest image the reference's i16 pixel arithmetic allows (fast.rs:116,122): 32767 columns."""
+    cfg, tiles = synth.scene("S2", 32767, 2, max_distance=5_000.0, fov=90.0, tilt=-10.0, level=301)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert got["hit_count"].shape == (2, 32767) and got["n_hits"] > 30000
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+    p = _abi.Params.from_buffer_copy(cfg.params)
+    p.width = 32768  # `x as i16` would wrap in the reference; rejected here
+    assert gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(p)) == _abi.ERR_INVALID_ARGUMENT

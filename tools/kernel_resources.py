@@ -6,10 +6,14 @@ import sys
 import os
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "atm-raytracer_amd", "csrc", "atmrt_kernels.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-c", src,
-       "-o", "/tmp/atmrt_k.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+units = [a for a in sys.argv[1:] if a.endswith(".hip")] or ["atmrt_kernels.hip", "atmrt_march_linear.hip"]
+flags = [a for a in sys.argv[1:] if not a.endswith(".hip")]
+out = ""
+for unit in units:
+    src = os.path.join(root, "atm-raytracer_amd", "csrc", unit)
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-c", src,
+           "-o", "/tmp/atmrt_k.o", "-Rpass-analysis=kernel-resource-usage"] + flags
+    out += subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)

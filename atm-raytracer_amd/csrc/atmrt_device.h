@@ -91,17 +91,6 @@ static __device__ __forceinline__ Earth earth_for(const Frame& f) {
   e.calc = CALC;
   return e;
 }
-// the stepping kernels exist with and without the Spline (cubic-segment) path of n(h)
-#define ATMRT_LAUNCH_MARCH(MODE, ...)                                                   \
-  do {                                                                                  \
-    if (f.atm_cubic) hipLaunchKernelGGL((k_rect_march<MODE, CALC, true>), __VA_ARGS__); \
-    else hipLaunchKernelGGL((k_rect_march<MODE, CALC, false>), __VA_ARGS__);            \
-  } while (0)
-#define ATMRT_LAUNCH_TRACE(FILL, ...)                                                   \
-  do {                                                                                  \
-    if (f.atm_cubic) hipLaunchKernelGGL((k_rect_trace<FILL, CALC, true>), __VA_ARGS__); \
-    else hipLaunchKernelGGL((k_rect_trace<FILL, CALC, false>), __VA_ARGS__);            \
-  } while (0)
 #define ATMRT_DISPATCH_CALC(calc, STMT)                  \
   switch (calc) {                                        \
     case 0: { constexpr int CALC = 0; STMT; } break;     \

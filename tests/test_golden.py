@@ -3,6 +3,7 @@ both oracle flavours must reproduce them on the CPU, and the HIP path must repro
 import glob
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -16,14 +17,9 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.n
 def load(path):
     z = np.load(path)
     meta = json.loads(str(z["meta"]))
-    spec = dict(meta["spec"])
-    import atm_raytracer_amd.synth as s  # rebuild the Config from the stored spec; the terrain comes from the fixture
-    orig = s.synth_tiles
-    s.synth_tiles = lambda *a, **k: {}
-    try:
-        cfg, _ = s.scene(spec.pop("scene"), spec.pop("w"), spec.pop("h"), generator=spec.pop("generator"), **spec)
-    finally:
-        s.synth_tiles = orig
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_golden  # the generating script also rebuilds the Config of a case (terrain comes from the fixture)
+    cfg, _ = make_golden.build_case(meta["spec"], with_terrain=False)
     tiles = {tuple(k): z[f"tile_{k[0]}_{k[1]}"] for k in meta["tile_keys"]}
     return cfg, tiles, z, meta
 
@@ -37,18 +33,28 @@ def check(res, z, meta, rtol):
 
 
 def test_fixtures_exist():
-    assert len(GOLDEN) >= 8
+    assert len(GOLDEN) >= 11
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 @pytest.mark.parametrize("flavour", ["det", "libm"])
 def test_oracle_reproduces_golden(path, flavour, oracle_det, oracle_libm):
     cfg, tiles, z, meta = load(path)
-    check(run_oracle(oracle_det if flavour == "det" else oracle_libm, cfg, tiles), z, meta, 1e-9)
+    oracle = oracle_det if flavour == "det" else oracle_libm
+    res = run_oracle(oracle, cfg, tiles)
+    check(res, z, meta, 1e-9)
+    img = oracle.draw_image(res, oracle.into_coloring(cfg.params, cfg.coloring)).astype(np.int16)
+    assert np.abs(img - z["image_rgb"].astype(np.int16)).max() <= (0 if flavour == "libm" else 1)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_gpu_reproduces_golden(path, gpu_ctx):
     cfg, tiles, z, meta = load(path)
-    check(run_gpu(gpu_ctx, cfg, tiles), z, meta, 1e-9)
+    import ctypes as C
+    from atm_raytracer_amd import config, generators
+    res = run_gpu(gpu_ctx, cfg, tiles)
+    check(res, z, meta, 1e-9)
+    img = generators.draw_image(gpu_ctx, generators.into_coloring(gpu_ctx.lib, cfg.params, cfg.coloring), res["width"], res["height"])
+    assert np.abs(img.astype(np.int16) - z["image_rgb"].astype(np.int16)).max() <= 1  # det vs libm: at most one 8-bit level
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(config.us76())))

@@ -32,12 +32,12 @@ def log(*a):
 
 def cpu_baseline(generator, seconds_budget=30.0):
     """The oracle (CPU restatement of the reference, glibc-libm flavour, OpenMP over all host cores) on a
-    bounded sample of the same scene: the headline frame at 1/2 (Fast) or 1/16 (Rectilinear) of the pixels
+    bounded sample of the same scene: the full headline frame (Fast / InterpolatingRectilinear) or 1/16 of its pixels (Rectilinear)
     with identical step / max_distance / field of view (about 10-30 s of CPU work on 16 threads)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
     from atm_raytracer_amd import synth
-    w, h = (4096, 1024) if generator == "Fast" else (1024, 512)
+    w, h = (4096, 2048) if generator != "Rectilinear" else (1024, 512)
     cfg, tiles = synth.scene("headline", w, h, generator=generator, level=1)
     oracle = Oracle("libm")
     t = oracle.terrain_new(tiles)

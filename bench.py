@@ -63,9 +63,12 @@ def main():
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--dted-level", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--also-fast", action="store_true", help="also time the Fast generator and report it under 'fast'")
+    ap.add_argument("--also-fast", action="store_true", help="(default behaviour) also time the Fast generator and report it under 'fast'")
+    ap.add_argument("--only", action="store_true", help="time only --generator, skip the secondary generators")
     ap.add_argument("--objects", type=int, default=0, help="BASELINE config 5: add N scene objects (70%% frusta, 30%% billboards)")
     ap.add_argument("--terrain-alpha", type=float, default=1.0)
+    ap.add_argument("--scene", default="headline", choices=["headline", "S2", "S3", "S4"], help="SURVEY §8(d) scene (tiles, observer, fov)")
+    ap.add_argument("--step", type=float, default=None, help="simulation_step override [m]")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,7 +100,7 @@ def main():
     wl = c1 - c0
 
     t_setup = time.perf_counter()
-    cfg, tiles = synth.scene("headline", W, H, generator=args.generator, level=args.dted_level)
+    cfg, tiles = synth.scene(args.scene, W, H, generator=args.generator, level=args.dted_level, step=args.step)
     cfg.params.col_begin, cfg.params.col_end = (c0, c1) if world > 1 else (0, 0)
     cfg.params.terrain_alpha = args.terrain_alpha
     if args.objects:
@@ -165,7 +168,8 @@ def main():
         the Fast path kernel stores 16 B per step of every row; the terrain profile reads 8 B and stores 8 B per sample."""
         mean = lambda k: float(np.mean([p[k] for p in phase]))
         steps_per_launch = mean("ray_steps")
-        n_path, n_t = 2003.0, 2000.0  # samples per ray at 100 m / 200 km (xs table; utils.rs:160-170, 191-196)
+        n_t = float(int(np.ceil(cfg.params.frame.max_distance / cfg.params.simulation_step)))  # samples per ray (utils.rs:191-196)
+        n_path = n_t + 3.0                                                                      # path elements per row (utils.rs:160-170)
         per_kernel = {
             "march_ms": ("k_rect_march", 8.0 * steps_per_launch + (8 + 8 + 4 + 4) * wl * H),
             "intersect_ms": ("k_fast_intersect", 8.0 * steps_per_launch + 8.0 * wl * H),
@@ -210,19 +214,26 @@ def main():
         "value": marched / elapsed, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"headline {W}x{H} panorama, 3x3 synthetic DTED level-{args.dted_level} tiles, step 100 m, max_distance 200 km, "
-                               f"spherical Earth + US-76 refraction, fov 120, generator {args.generator}",
+        "config": {"workload": f"{args.scene} {W}x{H} panorama, {len(tiles)} synthetic DTED level-{args.dted_level} tiles, step {cfg.params.simulation_step:g} m, "
+                               f"max_distance {cfg.params.frame.max_distance / 1000:g} km, spherical Earth + US-76 refraction, fov {cfg.params.frame.fov:g}, "
+                               f"generator {args.generator}", "scene": args.scene,
                    "generator": args.generator, "width": W, "height": H, "objects": args.objects, "terrain_alpha": args.terrain_alpha, "parallelism": f"pixel-column tiles x{world}" if world > 1 else "single GPU"},
         "mpixels_per_s": W * H * args.steps / elapsed / 1e6,
-        "ray_steps_per_frame": marched / args.steps,
+        "ray_steps_per_frame": marched / args.steps,   # marched under the reference's termination rule (the `value`)
+        "ray_steps_nominal_per_frame": float(W) * H * float(int(cfg.params.frame.max_distance / cfg.params.simulation_step)),  # if no ray terminated early
         "value_per_gpu": marched / elapsed / world,
         "roofline": roofline(args.generator, phase),
     }
-    if args.also_fast and args.generator != "Fast":
+    if not args.only and args.generator == "Rectilinear":
+        # the reference's other two generators on the same workload (secondary lines; `value` above is the per-pixel march)
         e2, m2, ph2 = timed("Fast", args.steps, 1)
         result["fast"] = {"value": m2 / e2, "unit": "ray-steps/s", "ms_per_step": e2 / args.steps * 1e3,
                           "mpixels_per_s": W * H * args.steps / e2 / 1e6, "roofline": roofline("Fast", ph2),
                           "note": "reference's default generator (params.rs:427-429): per-column terrain profile + per-row ray path"}
+        e3, m3, ph3 = timed("InterpolatingRectilinear", args.steps, 1)
+        result["interpolating_rectilinear"] = {"value": m3 / e3, "unit": "ray-steps/s", "ms_per_step": e3 / args.steps * 1e3,
+                                               "mpixels_per_s": W * H * args.steps / e3 / 1e6,
+                                               "note": "lattice of Fast-style pixels + 4-corner blend (interpolating_rectilinear.rs)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(args.generator)

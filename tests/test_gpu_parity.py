@@ -186,3 +186,38 @@ def test_objects_in_a_line_overflow_the_candidate_list(gpu_ctx, oracle_det):
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert (got["color_tag"] == 1).sum() > 20
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
+EARTHS = ["SimpleSphere", {"Spherical": {"radius": 6371000.0}}, {"Spherical": {"radius": 3.0e6}}, "Wgs84",
+          {"Ellipsoid": {"a": 6378137.0, "b": 6300000.0}}, "AzimuthalEquidistant", "FlatDistorted",
+          {"ObserverAe": {"proj_radius": 6371000.0}}, "SimpleObserverAe"]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_configurations(gpu_ctx, oracle_det, seed):
+    """Seeded random sweep over the parameter space (earth model, direction incl. the 0/360 wrap, tilt, field of view, observer
+    altitude kind, non-integer steps whose accumulated distances round, straight / refracted, opaque / translucent, generator,
+    wavelength): every f64 field and every hit decision must match the oracle bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
+    w, h = int(rng.integers(3, 70)), int(rng.integers(2, 40))
+    if gen == "Rectilinear":
+        w, h = min(w, 40), min(h, 24)
+    alt_kind = "Relative" if rng.uniform() < 0.5 else "Absolute"
+    doc = {
+        "view": {"position": {"latitude": float(rng.uniform(46.2, 46.8)), "longitude": float(rng.uniform(8.2, 8.8)),
+                              "altitude": {alt_kind: float(rng.uniform(1.0, 900.0) + (2500.0 if alt_kind == "Absolute" else 0.0))}},
+                 "frame": {"direction": float(rng.choice([rng.uniform(-30, 390), 0.0, 359.9, 180.0])), "tilt": float(rng.uniform(-25, 6)),
+                           "fov": float(rng.choice([rng.uniform(0.5, 140.0), 30.0])), "max_distance": float(rng.uniform(3_000.0, 70_000.0))}},
+        "earth_shape": EARTHS[int(rng.integers(len(EARTHS)))],
+        "straight_rays": bool(rng.uniform() < 0.25),
+        "simulation_step": float(rng.choice([rng.uniform(37.0, 400.0), 50.0, 33.3])),
+        "wavelength": float(rng.uniform(400e-9, 700e-9)),
+        "scene": {"terrain_alpha": float(rng.choice([1.0, 1.0, 0.5, 0.05]))},
+        "output": {"width": w, "height": h, "generator": gen},
+    }
+    from atm_raytracer_amd import config
+    cfg = config.Config.from_dict(doc)
+    tiles = synth.synth_tiles([46], [8], level=301)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))

@@ -210,6 +210,11 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
   constexpr int CH = 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Tile order: blockIdx.x = column tile, blockIdx.y = row group.  Consecutive workgroups share a row group (its ray
+  // elevations stay in the scalar cache / L2) and sweep the column tiles of the terrain profile.  An explicitly XCD-aware
+  // order (XCD r owns column tiles r, r+8, ... and walks all their row groups) was measured and rejected: FETCH_SIZE 0.50 GB
+  // vs 0.44 GB per frame and 2.46 ms vs 2.21 ms — the whole working set (65 MB profile + 33 MB paths) sits in the 256 MB
+  // Infinity Cache and the kernel is not bandwidth-limited.
   const int x = blockIdx.x * 64 + lane;
   const bool xok = x < f.wl;
   const int xc = xok ? x : f.wl - 1;

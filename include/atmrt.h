@@ -216,11 +216,13 @@ void atmrt_params_default(atmrt_params_t* p);         /* Config::default, params
 void atmrt_atmosphere_us76(atmrt_atmosphere_t* a);    /* AtmosphereDef::us_76 */
 int atmrt_set_params(atmrt_ctx* ctx, const atmrt_params_t* p);
 int atmrt_set_atmosphere(atmrt_ctx* ctx, const atmrt_atmosphere_t* a);
-int atmrt_objects_set(atmrt_ctx* ctx, const atmrt_object_t* objects, size_t n); /* scene.objects, in order */
+/* scene.objects, in order (object/mod.rs:156-190).  Billboard textures are copied during the call. */
+int atmrt_objects_set(atmrt_ctx* ctx, const atmrt_object_t* objects, size_t n);
 
 /* ---- the path ----------------------------------------------------------------------------- */
-/* Generator::generate for the generator named in params (generators/mod.rs:82-84).  The result is
- * library-allocated host memory; release with atmrt_result_free. */
+/* Generator::generate for the generator named in params (generators/mod.rs:82-84): Fast (fast.rs:22-98), Rectilinear
+ * (rectilinear.rs:24-60) or InterpolatingRectilinear (interpolating_rectilinear.rs:110-162), with or without scene objects and
+ * for any terrain_alpha.  The result is library-allocated host memory; release with atmrt_result_free. */
 int atmrt_generate(atmrt_ctx* ctx, atmrt_result_t* out);
 void atmrt_result_free(atmrt_result_t* r);
 /* Same computation, results left in HBM in caller-provided planes; ray_steps/device_ms optional. */

@@ -192,3 +192,24 @@ def test_maximum_width(gpu_ctx, oracle_det):
     p = _abi.Params.from_buffer_copy(cfg.params)
     p.width = 32768  # `x as i16` would wrap in the reference; rejected here
     assert gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(p)) == _abi.ERR_INVALID_ARGUMENT
+
+
+def test_two_contexts_compute_the_two_halves(oracle_det):
+    """Contexts are independent (one per rank in the multi-GPU layout): two of them on one device, each holding the terrain and
+    computing one pixel-column tile, together reproduce the whole frame."""
+    cfg, tiles = synth.scene("S2", 96, 40, terrain_alpha=0.5, tilt=-4.0, level=301)
+    want = run_oracle(oracle_det, cfg, tiles)
+    ctxs = [generators.Context(0), generators.Context(0)]
+    parts = []
+    for ctx, (c0, c1) in zip(ctxs, ((0, 37), (37, 96))):
+        terrain = generators.Terrain.from_tiles(tiles, ctx)
+        p = generators.Params(cfg)
+        p.pod = _abi.Params.from_buffer_copy(cfg.params)
+        p.pod.col_begin, p.pod.col_end = c0, c1
+        parts.append(generators.make_generator(p, terrain).generate())
+    for ctx in ctxs:
+        ctx.close()
+    for k in ("azimuth", "elevation_angle", "hit_count"):
+        assert np.array_equal(np.concatenate([r[k] for r in parts], axis=1), want[k]), k
+    assert parts[0]["ray_steps"] + parts[1]["ray_steps"] == want["ray_steps"]
+    assert parts[0]["n_hits"] + parts[1]["n_hits"] == want["n_hits"]

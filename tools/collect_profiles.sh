@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's roofline object cites, on the GPU box:
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh gpurun_out/final'
+# then, back in the container:  python3 tools/summarize_profiles.py gpurun_out/final profiles/r01 v4
+# Every pass runs the bench workload (3 timed frames) of ONE generator, so that a kernel shared between generators (the Fast
+# intersect scan also serves the interpolating lattice) is averaged over one use only; counters are collected in their own
+# passes, never together with a trace (MI355X_MICROARCH.md, HBM/rocprofv3 section).
+set -e
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/${1:-gpurun_out/final}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python3 $REPO/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+echo "[profiles] default bench done"
+SQ1="SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES"
+SQ2="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+for GEN in Rectilinear Fast InterpolatingRectilinear; do
+    BENCH="$REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --only --generator $GEN"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$GEN" -o t -- python3 $BENCH > "$OUT/bench_trace_$GEN.json" 2> "$OUT/trace_$GEN.err"
+    echo "[profiles] $GEN kernel trace done"
+    [ $GEN = InterpolatingRectilinear ] && continue
+    rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/fetch_$GEN" -o p -- python3 $BENCH > "$OUT/bench_fetch_$GEN.json" 2> "$OUT/fetch_$GEN.err"
+    rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/write_$GEN" -o p -- python3 $BENCH > "$OUT/bench_write_$GEN.json" 2> "$OUT/write_$GEN.err"
+    echo "[profiles] $GEN FETCH_SIZE / WRITE_SIZE done"
+    rocprofv3 --output-format csv --pmc $SQ1 -d "$OUT/sq1_$GEN" -o p -- python3 $BENCH > "$OUT/bench_sq1_$GEN.json" 2> "$OUT/sq1_$GEN.err"
+    rocprofv3 --output-format csv --pmc $SQ2 -d "$OUT/sq2_$GEN" -o p -- python3 $BENCH > "$OUT/bench_sq2_$GEN.json" 2> "$OUT/sq2_$GEN.err"
+    echo "[profiles] $GEN SQ passes done"
+done
+find "$OUT" -name "*.csv" -size +20M -delete   # keep what travels back small; the per-dispatch CSVs here are a few hundred KB

@@ -282,9 +282,9 @@ ATMRT_HD double atm_pressure(const AtmTable& a, double h) {
 ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   double t = temp - 273.15;
-  double pt = p / temp;
+  double pt = dm_div(p, temp);
   double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
-  return 1.0 + k_refr * pt / z;
+  return 1.0 + dm_div(k_refr * pt, z);
 }
 
 // a knot interval of a Spline temperature function
@@ -302,7 +302,7 @@ ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, dou
                              double expo, double h) {
   if (CUBIC && cubic) return refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h);
   double temp = tb + lapse * (h - hb);
-  double ratio = lapse != 0.0 ? dm_pow(temp / tb, expo) : dm_exp(expo * (h - hb));
+  double ratio = lapse != 0.0 ? dm_pow(dm_div(temp, tb), expo) : dm_exp(expo * (h - hb));
   return refr_from_tp(k_refr, temp, pb * ratio);
 }
 
@@ -341,7 +341,7 @@ ATMRT_HD double refr_dn_hint(const AtmTable& a, double h, int& hint) {
   const double eps = 0.01;
   double n1 = refr_n_hint<CUBIC>(a, h - eps, hint);
   double n2 = refr_n_hint<CUBIC>(a, h + eps, hint);
-  return (n2 - n1) / (2.0 * eps);
+  return dm_div(n2 - n1, 2.0 * eps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,11 +678,11 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
     double h = a - radius;
     double n = refr_n_hint<CUBIC>(atm, h, hint);
     double dn = refr_dn_hint<CUBIC>(atm, h, hint);
-    return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
+    return a + dm_div(2.0 * b * b, a) + dm_div((a * a + b * b) * dn, n);
   }
   double n = refr_n_hint<CUBIC>(atm, a, hint);
   double dn = refr_dn_hint<CUBIC>(atm, a, hint);
-  return (1.0 + b * b) * dn / n;
+  return dm_div((1.0 + b * b) * dn, n);
 }
 
 // PathStepper::next: the state after one more step of `step` metres in x.  `accel(spherical, radius, a, b, hint)` is

@@ -101,12 +101,12 @@ struct OctetRK4 {
     const double a1 = __shfl(nv, base + 1, 64), a2 = __shfl(nv, base + 2, 64);
     n_b = __shfl(nv, base + 4, 64);
     const double b1 = __shfl(nv, base + 5, 64), b2 = __shfl(nv, base + 6, 64);
-    dn_a = (a2 - a1) / (2.0 * eps);
-    dn_b = (b2 - b1) / (2.0 * eps);
+    dn_a = dm_div(a2 - a1, 2.0 * eps);
+    dn_b = dm_div(b2 - b1, 2.0 * eps);
   }
   static __device__ __forceinline__ double accel(bool spherical, double a, double b, double n, double dn) {
-    if (spherical) return a + 2.0 * b * b / a + (a * a + b * b) * dn / n;
-    return (1.0 + b * b) * dn / n;
+    if (spherical) return a + dm_div(2.0 * b * b, a) + dm_div((a * a + b * b) * dn, n);
+    return dm_div((1.0 + b * b) * dn, n);
   }
 
   // PathStepper::next, identical in value to stepper_next_with

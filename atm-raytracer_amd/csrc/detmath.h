@@ -52,6 +52,28 @@ DM_FN double dm_sqrt(double x) { return __builtin_sqrt(x); } /* correctly rounde
 DM_FN double dm_to_radians(double deg) { return deg * DM_RAD_PER_DEG; }
 DM_FN double dm_to_degrees(double rad) { return rad * DM_DEG_PER_RAD; }
 
+/* ---- division ---------------------------------------------------------------------------- */
+
+/* a / b for call sites whose operands are finite, b is non-zero and a, b, a/b and 1/b lie well inside the normal range
+ * (|exponent| < 500; a may also be +0).  On the host this IS the IEEE division.  On gfx950 the compiler expands `/` into
+ * v_div_scale x2, v_rcp, two Newton steps on the reciprocal, q = a r, one residual correction, v_div_fmas, v_div_fixup;
+ * for operands in that range the scaling steps multiply by 1 and the fix-up passes the quotient through, so the same
+ * sequence without them returns the same bits with 8 instructions instead of 11.  (78 divisions per RK4 step.) */
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN double dm_div(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = a * r;
+  e = __builtin_fma(-b, q, a);
+  return __builtin_fma(e, r, q);
+}
+#else
+DM_FN double dm_div(double a, double b) { return a / b; }
+#endif
+
 /* ---- sin / cos ------------------------------------------------------------------------- */
 
 /* x = n*(pi/2) + (y0 + y1), |y0| <= ~pi/4.  Three-term Cody–Waite; the first two terms have 33
@@ -294,7 +316,7 @@ DM_FN double dm_exp(double x) {
   r = hi - lo;
   t = r * r;
   c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-  y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  y = 1.0 - ((lo - dm_div(r * c, 2.0 - c)) - hi);
   return y * dm_from_bits((uint64_t)((int64_t)fk + 1023) << 52); /* |k| <= 1010 here */
 }
 
@@ -313,7 +335,7 @@ DM_FN double dm_log_core(double x, int64_t k) { /* x positive and normal */
   x = dm_from_bits(ix);
   f = x - 1.0;
   hfsq = 0.5 * f * f;
-  s = f / (2.0 + f);
+  s = dm_div(f, 2.0 + f);
   z = s * s;
   w = z * z;
   t1 = w * (Lg2 + w * (Lg4 + w * Lg6));

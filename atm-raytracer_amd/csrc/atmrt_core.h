@@ -306,6 +306,59 @@ ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, dou
   return refr_from_tp(k_refr, temp, pb * ratio);
 }
 
+// refr_n_layer at three points of one layer.  Same values as three calls; on the GPU the range guards of log and exp are
+// taken once per wavefront (a vote), so that the three pow evaluations form one basic block and their table look-ups overlap.
+ATMRT_HD void pow3(double x0, double x1, double x2, double y, double& r0, double& r1, double& r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__all(dm_log_in_main_range(x0) && dm_log_in_main_range(x1) && dm_log_in_main_range(x2))) {
+    const double e0 = y * dm_log_core(x0, 0), e1 = y * dm_log_core(x1, 0), e2 = y * dm_log_core(x2, 0);
+    if (__all(dm_exp_in_main_range(e0) && dm_exp_in_main_range(e1) && dm_exp_in_main_range(e2))) {
+      r0 = dm_exp_main(e0);
+      r1 = dm_exp_main(e1);
+      r2 = dm_exp_main(e2);
+      return;
+    }
+    r0 = dm_exp(e0);
+    r1 = dm_exp(e1);
+    r2 = dm_exp(e2);
+    return;
+  }
+#endif
+  r0 = dm_pow(x0, y);
+  r1 = dm_pow(x1, y);
+  r2 = dm_pow(x2, y);
+}
+ATMRT_HD void exp3(double e0, double e1, double e2, double& r0, double& r1, double& r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__all(dm_exp_in_main_range(e0) && dm_exp_in_main_range(e1) && dm_exp_in_main_range(e2))) {
+    r0 = dm_exp_main(e0);
+    r1 = dm_exp_main(e1);
+    r2 = dm_exp_main(e2);
+    return;
+  }
+#endif
+  r0 = dm_exp(e0);
+  r1 = dm_exp(e1);
+  r2 = dm_exp(e2);
+}
+template <bool CUBIC = true>
+ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3, double expo,
+                            double h0, double h1, double h2, double& n0, double& n1, double& n2) {
+  if (CUBIC && cubic) {
+    n0 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
+    n1 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
+    n2 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h2);
+    return;
+  }
+  const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
+  double r0, r1, r2;
+  if (lapse != 0.0) pow3(dm_div(t0, tb), dm_div(t1, tb), dm_div(t2, tb), expo, r0, r1, r2);
+  else exp3(expo * (h0 - hb), expo * (h1 - hb), expo * (h2 - hb), r0, r1, r2);
+  n0 = refr_from_tp(k_refr, t0, pb * r0);
+  n1 = refr_from_tp(k_refr, t1, pb * r1);
+  n2 = refr_from_tp(k_refr, t2, pb * r2);
+}
+
 // Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).
 ATMRT_HD double refr_n(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
@@ -342,6 +395,30 @@ ATMRT_HD double refr_dn_hint(const AtmTable& a, double h, int& hint) {
   double n1 = refr_n_hint<CUBIC>(a, h - eps, hint);
   double n2 = refr_n_hint<CUBIC>(a, h + eps, hint);
   return dm_div(n2 - n1, 2.0 * eps);
+}
+
+// n(h) and dn/dh(h) of one ODE right-hand side: the three evaluations at h, h - eps and h + eps.  When all three points of
+// every active lane lie in the hinted layer (they are 1 cm apart), one check and one set of scalar layer parameters serve the
+// three evaluations and their instruction streams interleave (the table look-ups of exp/log are the long latencies here).
+template <bool CUBIC>
+ATMRT_HD void refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, double& dn) {
+  const double eps = 0.01;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ku = __builtin_amdgcn_readfirstlane(hint);
+  const double h1 = h - eps, h2 = h + eps;
+  const bool ok = (ku == 0 || h1 >= a.from[ku]) && (ku == a.n - 1 || h2 < a.from[ku + 1]);
+  if (__all(ok)) {
+    const double k_refr = a.k_refr, hb = a.hb[ku], tb = a.tb[ku], pb = a.pb[ku], lapse = a.lapse[ku], c2 = a.c2[ku], c3 = a.c3[ku],
+                 expo = a.expo[ku];
+    const int cubic = a.cubic[ku];
+    double n1, n2;
+    refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
+    dn = dm_div(n2 - n1, 2.0 * eps);
+    return;
+  }
+#endif
+  n = refr_n_hint<CUBIC>(a, h, hint);
+  dn = refr_dn_hint<CUBIC>(a, h, hint);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,12 +753,12 @@ template <bool CUBIC>
 ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b, int& hint) {
   if (spherical) {
     double h = a - radius;
-    double n = refr_n_hint<CUBIC>(atm, h, hint);
-    double dn = refr_dn_hint<CUBIC>(atm, h, hint);
+    double n, dn;
+    refr_n_dn_hint<CUBIC>(atm, h, hint, n, dn);
     return a + dm_div(2.0 * b * b, a) + dm_div((a * a + b * b) * dn, n);
   }
-  double n = refr_n_hint<CUBIC>(atm, a, hint);
-  double dn = refr_dn_hint<CUBIC>(atm, a, hint);
+  double n, dn;
+  refr_n_dn_hint<CUBIC>(atm, a, hint, n, dn);
   return dm_div((1.0 + b * b) * dn, n);
 }
 

@@ -18,6 +18,7 @@
 #define ATMRT_DETMATH_H
 
 #include <stdint.h>
+#include "detmath_tables.h"
 
 #ifndef DM_FN
 #define DM_FN static inline
@@ -51,6 +52,15 @@ DM_FN double dm_rint(double x) { return __builtin_rint(x); } /* ties-to-even */
 DM_FN double dm_sqrt(double x) { return __builtin_sqrt(x); } /* correctly rounded (verified on gfx950 by tests) */
 DM_FN double dm_to_radians(double deg) { return deg * DM_RAD_PER_DEG; }
 DM_FN double dm_to_degrees(double rad) { return rad * DM_DEG_PER_RAD; }
+
+/* Fused multiply-add (one rounding) and exact scaling by 2^e.  detmath's own polynomials and reductions use them on both
+ * sides; the formulas restated from the reference never do (Rust does not contract a*b+c). */
+#define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_SCALBN(y, e) __builtin_ldexp((y), (e))
+#else
+#define DM_SCALBN(y, e) ((y) * dm_from_bits((uint64_t)((int64_t)(e) + 1023) << 52)) /* |e| < 1022 */
+#endif
 
 /* ---- division ---------------------------------------------------------------------------- */
 
@@ -273,7 +283,7 @@ DM_FN double dm_asin(double x) {
 
 /* ---- exp / log / pow ------------------------------------------------------------------- */
 
-DM_FN double dm_exp_slow(double x) { /* |x| < 2^-28, |x| > 700, nan */
+DM_FN double dm_exp_slow(double x) { /* |x| > 700, nan (K.C. Ng's form; not on any hot path) */
   const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00;
   const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
@@ -299,50 +309,60 @@ DM_FN double dm_exp_slow(double x) { /* |x| < 2^-28, |x| > 700, nan */
   return (y * dm_from_bits((uint64_t)(k + 1000 + 1023) << 52)) * dm_from_bits((uint64_t)(1023 - 1000) << 52);
 }
 
-/* exp(x) = 2^k exp(r), r = x - k ln2 in [-ln2/2, ln2/2]; exp(r) = 1 + r + r c/(2 - c) (K.C. Ng's form).
- * The main range 2^-28 <= |x| <= 700 is one straight line (for |x| <= ln2/2 the reduction gives k = 0 and
- * r = x exactly, so no small-argument branch is needed); everything else goes to dm_exp_slow. */
+/* exp(x) = 2^e 2^(j/128) e^r with x = (128 e + j) ln2/128 + r, |r| <= ln2/256 (Tang's table-driven reduction; the table
+ * holds 2^(j/128) as a double-double, e^r - 1 is the degree-5 Taylor polynomial: r^6/720 < 2^-60).  Both reduction steps are
+ * single FMAs (the first is exact: kd ln2N_hi and x share their bits above 2^-60).  One straight line for |x| <= 700
+ * (for |x| <= ln2/256 kd = 0 and r = x exactly); everything else goes to dm_exp_slow.  < 0.6 ulp. */
+DM_FN double dm_exp_main(double x) { /* |x| <= 700 */
+  double kd, r, r2, q, p, s, y;
+  const double* t;
+  int32_t ki, e;
+  kd = dm_rint(x * DM_INVLN2N);
+  ki = (int32_t)kd;
+  r = DM_FMA(-kd, DM_LN2N_HI, x);
+  r = DM_FMA(-kd, DM_LN2N_LO, r);
+  t = DM_EXP_TAB[ki & 127];
+  e = ki >> 7;
+  r2 = r * r;
+  q = DM_FMA(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  q = DM_FMA(r, q, 1.66666666666666667e-01);
+  q = DM_FMA(r, q, 0.5);
+  p = DM_FMA(r2, q, r);
+  s = DM_FMA(t[0], p, t[1]);
+  y = t[0] + s;
+  return DM_SCALBN(y, e); /* |e| <= 1010: the result is normal */
+}
+DM_FN int dm_exp_in_main_range(double x) { return dm_fabs(x) <= 700.0; } /* false for NaN */
 DM_FN double dm_exp(double x) {
-  const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
-               invln2 = 1.44269504088896338700e+00;
-  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-               P5 = 4.13813679705723846039e-08;
-  double ax = dm_fabs(x), fk, hi, lo, r, t, c, y;
-  if (!(ax >= 3.725290298461914e-09 && ax <= 700.0)) return dm_exp_slow(x);
-  fk = dm_rint(x * invln2);
-  hi = x - fk * ln2hi;
-  lo = fk * ln2lo;
-  r = hi - lo;
-  t = r * r;
-  c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-  y = 1.0 - ((lo - dm_div(r * c, 2.0 - c)) - hi);
-  return y * dm_from_bits((uint64_t)((int64_t)fk + 1023) << 52); /* |k| <= 1010 here */
+  if (!dm_exp_in_main_range(x)) return dm_exp_slow(x);
+  return dm_exp_main(x);
 }
 
-DM_FN double dm_log_core(double x, int64_t k) { /* x positive and normal */
-  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-               Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-               Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-               Lg7 = 1.479819860511658591e-01;
+/* log(x) for positive normal x: x = 2^k z with z within half a step of one of 128 centres c (7 mantissa bits, from 0.707 to
+ * 1.406; the centre of the interval around 1 is exactly 1), r = z/c - 1 by one FMA with the tabulated 1/c (|r| <= 2^-8),
+ * log x = k ln2 + log c + log1p(r); log c = -log(invc) is tabulated as a double-double, log1p(r) is the degree-7 Taylor
+ * polynomial (r^8/8 < 2^-67).  k ln2_hi and logc_hi are multiples of 2^-42, so w below is exact; the rest of the sum is
+ * accumulated as hi + lo like a double-double.  < 0.85 ulp (the worst cases sit next to the interval around 1). */
+DM_FN double dm_log_core(double x, int32_t k0) {
   uint64_t ix = dm_bits(x);
-  double f, s, z, w, t1, t2, R, hfsq, dk;
-  /* normalise to [sqrt(2)/2, sqrt(2)) */
-  ix += 0x3ff0000000000000ULL - 0x3fe6a09e00000000ULL;
-  k += (int64_t)(ix >> 52) - 1023;
-  ix = (ix & 0x000fffffffffffffULL) + 0x3fe6a09e00000000ULL;
-  x = dm_from_bits(ix);
-  f = x - 1.0;
-  hfsq = 0.5 * f * f;
-  s = dm_div(f, 2.0 + f);
-  z = s * s;
-  w = z * z;
-  t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-  t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
-  R = t2 + t1;
-  dk = (double)k;
-  return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+  uint32_t hi = (uint32_t)(ix >> 32);
+  int32_t u = (int32_t)(((hi + 0x1000u) & 0xffffe000u) - 0x3fe6a000u); /* nearest centre, relative to 0.70703125 */
+  int32_t k = u >> 20;
+  const double* t = DM_LOG_TAB[(u >> 13) & 127];
+  double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)(hi - ((uint32_t)u & 0xfff00000u)) << 32));
+  double r = DM_FMA(z, t[0], -1.0);
+  double kd = (double)(k + k0);
+  double w = DM_FMA(kd, DM_LN2_HI, t[1]);
+  double h = w + r;
+  double l = (w - h) + r;
+  double r2 = r * r, p;
+  l = l + DM_FMA(kd, DM_LN2_LO, t[2]);
+  p = DM_FMA(r, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  p = DM_FMA(r, p, 0.2);
+  p = DM_FMA(r, p, -0.25);
+  p = DM_FMA(r, p, 3.33333333333333333e-01);
+  p = DM_FMA(r, p, -0.5);
+  return DM_FMA(r2, p, l) + h;
 }
 DM_FN double dm_log_slow(double x) { /* nan, negative, zero, inf, subnormal */
   if (dm_isnan(x)) return x + x;
@@ -351,8 +371,9 @@ DM_FN double dm_log_slow(double x) { /* nan, negative, zero, inf, subnormal */
   if (dm_isinf(x)) return x;
   return dm_log_core(x * 18014398509481984.0, -54); /* subnormal: scale by 2^54 */
 }
+DM_FN int dm_log_in_main_range(double x) { return x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308; }
 DM_FN double dm_log(double x) {
-  if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return dm_log_slow(x);
+  if (!dm_log_in_main_range(x)) return dm_log_slow(x);
   return dm_log_core(x, 0);
 }
 

@@ -11,8 +11,9 @@ def _build(src, out, cmd):
     src, out = os.path.join(HERE, "csrc", src), os.path.join(OUT, out)
     deps = [src, os.path.join(HERE, "..", "atm-raytracer_amd", "csrc", "detmath.h"),
             os.path.join(HERE, "..", "atm-raytracer_amd", "csrc", "atmrt_core.h")]
+    deps.append(os.path.join(HERE, "..", "atm-raytracer_amd", "csrc", "detmath_tables.h"))
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(cmd + ["-o", out, src], check=True)
+        subprocess.run(cmd + ["-o", out, src, "-lm"], check=True)  # -lm: fma() when the build has no -mfma
     return out
 
 

@@ -406,11 +406,14 @@ ATMRT_HD void refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
 #if defined(__HIP_DEVICE_COMPILE__)
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   const double h1 = h - eps, h2 = h + eps;
-  const bool ok = (ku == 0 || h1 >= a.from[ku]) && (ku == a.n - 1 || h2 < a.from[ku + 1]);
+  // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
+  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
+  const ConstTable ka = (ConstTable)(uintptr_t)&a;
+  const bool ok = (ku == 0 || h1 >= ka->from[ku]) && (ku == ka->n - 1 || h2 < ka->from[ku + 1]);
   if (__all(ok)) {
-    const double k_refr = a.k_refr, hb = a.hb[ku], tb = a.tb[ku], pb = a.pb[ku], lapse = a.lapse[ku], c2 = a.c2[ku], c3 = a.c3[ku],
-                 expo = a.expo[ku];
-    const int cubic = a.cubic[ku];
+    const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
+                 c3 = ka->c3[ku], expo = ka->expo[ku];
+    const int cubic = ka->cubic[ku];
     double n1, n2;
     refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
     dn = dm_div(n2 - n1, 2.0 * eps);

@@ -3,9 +3,25 @@
 // (atmrt_march_linear.hip, atmrt_march_spline.hip) that instantiate the launchers for atmospheres without / with Spline
 // segments, so the heavy template variants (3 modes x 4 DirectionalCalc kinds x 2) compile in parallel.
 #pragma once
+// exp/log tables of detmath.h in LDS for this translation unit (6 KB per block): every kernel below calls stage_dm_tables() first.
+// The look-ups sit on the dependent chain of each n(h) evaluation; from LDS they cost ~1/3 of an L1 hit.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_TABLES_LDS atmrt_dm_tables_lds
+__shared__ double atmrt_dm_tables_lds[768];
+#endif
 #include "atmrt_device.h"
 
 namespace atmrt {
+
+__device__ __forceinline__ void stage_dm_tables() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double* lt = &DM_LOG_TAB[0][0];
+  const double* et = &DM_EXP_TAB[0][0];
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) atmrt_dm_tables_lds[i] = lt[i];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) atmrt_dm_tables_lds[512 + i] = et[i];
+  __syncthreads();
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // Rectilinear generator: one ray per lane — per-step geodesic point, bilinear terrain gather
@@ -26,6 +42,7 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters) {
+  stage_dm_tables();
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = p < plane;
@@ -122,6 +139,7 @@ static __device__ __forceinline__ TracePointDev rect_hit(const Frame& f, int x, 
 template <int CALC>
 __global__ __launch_bounds__(256) void k_rect_finalize(Frame f, const int32_t* __restrict__ hit_step, RectRec rec,
                                                        DensePlanes out) {
+  stage_dm_tables();
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
@@ -139,6 +157,7 @@ __global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_
                                                             const uint32_t* __restrict__ list_step,
                                                             const uint32_t* __restrict__ list_pixel, RectRec rec,
                                                             PackedHits packed) {
+  stage_dm_tables();
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_hits) return;
   if (f.n_objects && packed.color_tag[k] != ATMRT_COLOR_TERRAIN) return; // object points are already complete
@@ -197,6 +216,7 @@ __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, co
                                                     PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
                                                     uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters) {
+  stage_dm_tables();
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long steps = 0;

@@ -281,6 +281,16 @@ DM_FN double dm_asin(double x) {
   return dm_copysign(res, x);
 }
 
+/* Where the tables of exp and log are read from: the constant arrays of detmath_tables.h, or — in a GPU translation unit that
+ * defines DM_TABLES_LDS as a __shared__ double[768] which each of its kernels fills first (log rows, then exp rows) — from LDS. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DM_TABLES_LDS)
+#define DM_LOG_ROW(i) (&DM_TABLES_LDS[4 * (i)])
+#define DM_EXP_ROW(j) (&DM_TABLES_LDS[512 + 2 * (j)])
+#else
+#define DM_LOG_ROW(i) DM_LOG_TAB[i]
+#define DM_EXP_ROW(j) DM_EXP_TAB[j]
+#endif
+
 /* ---- exp / log / pow ------------------------------------------------------------------- */
 
 DM_FN double dm_exp_slow(double x) { /* |x| > 700, nan (K.C. Ng's form; not on any hot path) */
@@ -321,7 +331,7 @@ DM_FN double dm_exp_main(double x) { /* |x| <= 700 */
   ki = (int32_t)kd;
   r = DM_FMA(-kd, DM_LN2N_HI, x);
   r = DM_FMA(-kd, DM_LN2N_LO, r);
-  t = DM_EXP_TAB[ki & 127];
+  t = DM_EXP_ROW(ki & 127);
   e = ki >> 7;
   r2 = r * r;
   q = DM_FMA(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
@@ -348,7 +358,7 @@ DM_FN double dm_log_core(double x, int32_t k0) {
   uint32_t hi = (uint32_t)(ix >> 32);
   int32_t u = (int32_t)(((hi + 0x1000u) & 0xffffe000u) - 0x3fe6a000u); /* nearest centre, relative to 0.70703125 */
   int32_t k = u >> 20;
-  const double* t = DM_LOG_TAB[(u >> 13) & 127];
+  const double* t = DM_LOG_ROW((u >> 13) & 127);
   double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)(hi - ((uint32_t)u & 0xfff00000u)) << 32));
   double r = DM_FMA(z, t[0], -1.0);
   double kd = (double)(k + k0);

@@ -59,6 +59,7 @@ struct AtmTable {
   double c3[ATMRT_MAX_ATM_SEGMENTS];
   int32_t cubic[ATMRT_MAX_ATM_SEGMENTS];
   double k_refr;                        // (n - 1) = k_refr * (p/T) / Z
+  double rtb[ATMRT_MAX_ATM_SEGMENTS];   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
 };
 
 ATMRT_HD int atm_layer(const AtmTable& a, double h) {
@@ -108,7 +109,7 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
   const int nf = def.n_functions;
   if (nf < 1 || nf > ATMRT_MAX_ATM_FUNCTIONS) return -1;
   for (int k = 0; k < ATMRT_MAX_ATM_SEGMENTS; k++) {
-    out.hb[k] = out.tb[k] = out.pb[k] = out.lapse[k] = out.from[k] = out.expo[k] = out.c2[k] = out.c3[k] = 0.0;
+    out.hb[k] = out.tb[k] = out.pb[k] = out.lapse[k] = out.from[k] = out.expo[k] = out.c2[k] = out.c3[k] = out.rtb[k] = 0.0;
     out.cubic[k] = 0;
   }
   out._pad = 0;
@@ -245,8 +246,10 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
       }
     }
   }
-  for (int k = 0; k < n; k++)
+  for (int k = 0; k < n; k++) {
     out.expo[k] = out.cubic[k] ? -gmr : (out.lapse[k] != 0.0 ? -gmr / out.lapse[k] : -gmr / out.tb[k]);
+    out.rtb[k] = 1.0 / out.tb[k];
+  }
   // ---- pressure: chain outwards from the pressure fixed point
   int jp = atm_layer(out, def.pressure_altitude);
   out.pb[jp] = def.pressure / atm_pressure_ratio(out, jp, def.pressure_altitude);
@@ -342,8 +345,8 @@ ATMRT_HD void exp3(double e0, double e1, double e2, double& r0, double& r1, doub
   r2 = dm_exp(e2);
 }
 template <bool CUBIC = true>
-ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3, double expo,
-                            double h0, double h1, double h2, double& n0, double& n1, double& n2) {
+ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, double rtb, double pb, double lapse, double c2, double c3,
+                            double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2) {
   if (CUBIC && cubic) {
     n0 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
     n1 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
@@ -352,7 +355,7 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, doub
   }
   const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
   double r0, r1, r2;
-  if (lapse != 0.0) pow3(dm_div(t0, tb), dm_div(t1, tb), dm_div(t2, tb), expo, r0, r1, r2);
+  if (lapse != 0.0) pow3(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
   else exp3(expo * (h0 - hb), expo * (h1 - hb), expo * (h2 - hb), r0, r1, r2);
   n0 = refr_from_tp(k_refr, t0, pb * r0);
   n1 = refr_from_tp(k_refr, t1, pb * r1);
@@ -411,12 +414,12 @@ ATMRT_HD void refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   const ConstTable ka = (ConstTable)(uintptr_t)&a;
   const bool ok = (ku == 0 || h1 >= ka->from[ku]) && (ku == ka->n - 1 || h2 < ka->from[ku + 1]);
   if (__all(ok)) {
-    const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
+    const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], rtb = ka->rtb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
                  c3 = ka->c3[ku], expo = ka->expo[ku];
     const int cubic = ka->cubic[ku];
     double n1, n2;
-    refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
-    dn = dm_div(n2 - n1, 2.0 * eps);
+    refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
+    dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
     return;
   }
 #endif
@@ -581,7 +584,7 @@ ATMRT_HD void dircalc_new(const Earth& e, double lat, double lon, double dir, Di
 // DirectionalCalc::coords_at_dist
 ATMRT_HD void coords_at_dist(const Earth& e, const DirCalc& c, double dist, double& lat, double& lon) {
   if (e.calc == 2) { // SphericalCalc, directional_calc.rs:72-85
-    double ang = dist / e.calc_radius;
+    double ang = dm_div(dist, e.calc_radius);
     double sinang, cosang;
     dm_sincos(ang, &sinang, &cosang);
     double fx = c.pos.x * cosang + c.dir.x * sinang;
@@ -832,10 +835,11 @@ ATMRT_HD bool atm_has_cubic(const AtmTable& a) {
 ATMRT_HD double calc_dist(bool spherical, double radius, double x0, double h0, double x1, double h1) {
   double dx = x1 - x0;
   double dh = h1 - h0;
-  if (!spherical) return dm_sqrt(dx * dx + dh * dh);
+  // every caller advances by one simulation step: dx > 0 (validated by atmrt_set_params), so the radicand is positive and finite
+  if (!spherical) return dm_sqrt_inrange(dx * dx + dh * dh);
   double avg_h = (h1 + h0) / 2.0;
-  double dx2 = dx / radius * (avg_h + radius);
-  return dm_sqrt(dx2 * dx2 + dh * dh);
+  double dx2 = dm_div(dx, radius) * (avg_h + radius);
+  return dm_sqrt_inrange(dx2 * dx2 + dh * dh);
 }
 
 // ---------------------------------------------------------------------------------------------

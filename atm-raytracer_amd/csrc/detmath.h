@@ -84,6 +84,44 @@ DM_FN double dm_div(double a, double b) {
 DM_FN double dm_div(double a, double b) { return a / b; }
 #endif
 
+/* a / b given y = RN(1/b) (a correctly rounded reciprocal, e.g. tabulated on the host): two residual corrections.  After the
+ * first, q1 is a faithful quotient; with y correctly rounded the second then yields RN(a/b) (Markstein's theorem), for operands
+ * in the range described at dm_div.  5 instructions.  dm_div_r_seq is the sequence itself (tests/test_detmath.py checks it
+ * against `/` on the host); dm_div_r is what call sites use: the sequence on the GPU, the plain division on the host. */
+DM_FN double dm_div_r_seq(double a, double b, double y) {
+  double q = a * y;
+  double e = DM_FMA(-b, q, a);
+  q = DM_FMA(e, y, q);
+  e = DM_FMA(-b, q, a);
+  return DM_FMA(e, y, q);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN double dm_div_r(double a, double b, double y) { return dm_div_r_seq(a, b, y); }
+#else
+DM_FN double dm_div_r(double a, double b, double y) { (void)y; return a / b; }
+#endif
+
+/* sqrt(x) for x in the normal range well away from its ends (2^-500 < x < 2^500; not 0).  The host takes the IEEE square root.
+ * gfx950 expands sqrt into a scaling test, v_rsq, a coupled Newton iteration on (g ~ sqrt x, h ~ 1/(2 sqrt x)), two residual
+ * corrections, an unscaling and a class fix-up for 0/inf; for x in that range the scaling is by 2^0 and the fix-up passes g
+ * through, so the iteration alone returns the same bits with 10 instructions instead of 20. */
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN double dm_sqrt_inrange(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+#else
+DM_FN double dm_sqrt_inrange(double x) { return __builtin_sqrt(x); }
+#endif
+
 /* ---- sin / cos ------------------------------------------------------------------------- */
 
 /* x = n*(pi/2) + (y0 + y1), |y0| <= ~pi/4.  Three-term Cody–Waite; the first two terms have 33

@@ -5,3 +5,4 @@
 V1(sin) V1(cos) V1(tan) V1(asin) V1(atan) V1(exp) V1(log) V1(sqrt) V1(floor)
 void t_atan2(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
 void t_pow(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_pow(a[i], b[i]); }
+void t_div_r_seq(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_div_r_seq(a[i], b[i], 1.0 / b[i]); }

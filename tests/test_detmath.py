@@ -86,3 +86,19 @@ def test_special_values(dm):
     assert call1(dm, "log", [1.0])[0] == 0.0
     x = np.random.default_rng(5).uniform(0, 1e6, 100000)
     assert np.array_equal(call1(dm, "sqrt", x), np.sqrt(x))
+
+
+def test_division_by_tabulated_reciprocal(dm):
+    """dm_div_r_seq(a, b, RN(1/b)) — what the GPU uses for T/T_b and dn/(2 eps) — equals the IEEE quotient: the layer base
+    temperatures of US-76, 2 eps, and random denominators, 2e6 numerators each over the magnitudes the path sees."""
+    rng = np.random.default_rng(14)
+    for b in (288.15, 216.65, 228.65, 270.65, 214.65, 0.02, 6371000.0, 1.0, 3.0, 0.1):
+        for scale in (1.0, 1e-9, 1e6):
+            a = rng.uniform(-400.0, 400.0, 2_000_000) * scale
+            bb = np.full_like(a, b)
+            assert np.array_equal(call2(dm, "div_r_seq", a, bb), a / bb), (b, scale)
+    a, b = rng.uniform(-1e3, 1e3, 4_000_000), rng.uniform(1e-3, 1e3, 4_000_000) * rng.choice([-1.0, 1.0], 4_000_000)
+    assert np.array_equal(call2(dm, "div_r_seq", a, b), a / b)
+    a, b = np.exp(rng.uniform(-200, 200, 2_000_000)), np.exp(rng.uniform(-200, 200, 2_000_000))
+    assert np.array_equal(call2(dm, "div_r_seq", a, b), a / b)
+    assert np.array_equal(call2(dm, "div_r_seq", np.zeros(3), np.array([288.15, 0.02, 5.0])), np.zeros(3))

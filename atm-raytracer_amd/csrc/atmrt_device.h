@@ -81,6 +81,17 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
   return v;
 }
 
+// A translation unit that defines DM_TABLES_LDS (see detmath.h) calls this first in every kernel: exp/log tables -> LDS.
+__device__ __forceinline__ void stage_dm_tables() {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DM_TABLES_LDS)
+  const double* lt = &DM_LOG_TAB[0][0];
+  const double* et = &DM_EXP_TAB[0][0];
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) DM_TABLES_LDS[i] = lt[i];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) DM_TABLES_LDS[512 + i] = et[i];
+  __syncthreads();
+#endif
+}
+
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // The DirectionalCalc kind is a compile-time constant in the heavy kernels, so only one of the four

@@ -133,6 +133,7 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* tmp, uint64_t* out,
 void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                        hipStream_t stream);
+void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream); // atmrt_paths.hip
 void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,
                         hipEvent_t ev_join, hipEvent_t* timing /* [0..1] phase A, [2..3] phase B */);
 void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);

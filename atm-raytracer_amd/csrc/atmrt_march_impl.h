@@ -13,15 +13,6 @@ __shared__ double atmrt_dm_tables_lds[768];
 
 namespace atmrt {
 
-__device__ __forceinline__ void stage_dm_tables() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const double* lt = &DM_LOG_TAB[0][0];
-  const double* et = &DM_EXP_TAB[0][0];
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) atmrt_dm_tables_lds[i] = lt[i];
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) atmrt_dm_tables_lds[512 + i] = et[i];
-  __syncthreads();
-#endif
-}
 
 // ---------------------------------------------------------------------------------------------
 // Rectilinear generator: one ray per lane — per-step geodesic point, bilinear terrain gather

@@ -1,0 +1,142 @@
+// atmrt_paths.hip — phase B of the Fast generator: the per-row ray paths (gen_path_cache, utils.rs:136-174) on gfx950.
+// A translation unit of its own so that detmath's exp/log tables can live in LDS here (DM_TABLES_LDS): the kernel is one
+// long dependent chain per ray, and every table look-up of an n(h) evaluation sits on that chain.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_TABLES_LDS atmrt_dm_tables_lds
+__shared__ double atmrt_dm_tables_lds[768];
+#endif
+#include "atmrt_kernels.h"
+#include "atmrt_device.h"
+
+namespace atmrt {
+
+// Phase B.  Rows are independent and each ray is a sequential RK4 chain (H-way parallelism only), so the kernel is
+// latency-bound.  Two facts shorten the chain without touching the arithmetic:
+//   * the three n(h) evaluations behind one right-hand side (n(h), n(h - eps), n(h + eps) of Environment::n / dn) are
+//     independent of each other;
+//   * n and dn depend only on the POSITION argument of an RK4 stage, and stage 2's position a + d/2 k1a (k1a = b) is known
+//     when the step starts, likewise stage 4's position once k1b is known — so stages 1 and 2, then stages 3 and 4, can
+//     evaluate their refractive indices concurrently.
+// Each ray therefore gets an OCTET of lanes: lanes 0-2 serve stages 1 and 3, lanes 4-6 stages 2 and 4 (lanes 3 and 7
+// duplicate); values are exchanged with shuffles and the cheap remainder is computed redundantly by all eight lanes.
+// Same operations in the same order per value; a quarter of the dependent chain of the one-lane-per-ray version.
+template <bool CUBIC>
+struct OctetRK4 {
+  const AtmTable& atm;
+  int sub, base; // lane within the octet, first lane of the octet within the wavefront
+
+  // n and dn at position `pos` for both stage groups: this lane evaluates its share, everyone receives both results
+  __device__ __forceinline__ void eval(bool spherical, double radius, double pos_a, double pos_b, int& hint, double& n_a,
+                                       double& dn_a, double& n_b, double& dn_b) const {
+    const double eps = 0.01;
+    const double pos = (sub & 4) ? pos_b : pos_a;
+    const double h = spherical ? pos - radius : pos;
+    const int e = sub & 3;
+    const double hh = e == 1 ? h - eps : e == 2 ? h + eps : h;
+    const double nv = refr_n_hint<CUBIC>(atm, hh, hint);
+    n_a = __shfl(nv, base, 64);
+    const double a1 = __shfl(nv, base + 1, 64), a2 = __shfl(nv, base + 2, 64);
+    n_b = __shfl(nv, base + 4, 64);
+    const double b1 = __shfl(nv, base + 5, 64), b2 = __shfl(nv, base + 6, 64);
+    dn_a = dm_div(a2 - a1, 2.0 * eps);
+    dn_b = dm_div(b2 - b1, 2.0 * eps);
+  }
+  static __device__ __forceinline__ double accel(bool spherical, double a, double b, double n, double dn) {
+    if (spherical) return a + dm_div(2.0 * b * b, a) + dm_div((a * a + b * b) * dn, n);
+    return dm_div((1.0 + b * b) * dn, n);
+  }
+
+  // PathStepper::next, identical in value to stepper_next_with
+  __device__ __forceinline__ RayState next(Stepper& s, bool spherical, double radius, bool straight, double step) const {
+    if (straight) return stepper_next_with(s, spherical, radius, true, step, SerialAccel<CUBIC>{atm});
+    const double d = spherical ? step / radius : step;
+    const double half = 0.5 * d, sixth = d / 6.0;
+    const double a = s.a, b = s.b;
+    double n1, dn1, n2, dn2, n3, dn3, n4, dn4;
+    const double k1a = b;
+    eval(spherical, radius, a, a + half * k1a, s.hint, n1, dn1, n2, dn2);
+    const double k1b = accel(spherical, a, b, n1, dn1);
+    const double k2a = b + half * k1b;
+    const double k2b = accel(spherical, a + half * k1a, k2a, n2, dn2);
+    const double k3a = b + half * k2b;
+    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, n3, dn3, n4, dn4);
+    const double k3b = accel(spherical, a + half * k2a, k3a, n3, dn3);
+    const double k4a = b + d * k3b;
+    const double k4b = accel(spherical, a + d * k3a, k4a, n4, dn4);
+    s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
+    s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
+    s.x = s.x + step;
+    RayState out;
+    out.x = s.x;
+    if (spherical) {
+      out.h = s.a - radius;
+      out.dh = s.b / radius;
+    } else {
+      out.h = s.a;
+      out.dh = s.b;
+    }
+    return out;
+  }
+};
+
+constexpr int PATH_LANES = 8; // lanes per ray
+
+template <bool CUBIC>
+__global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__ pelev, double* __restrict__ plen,
+                                                   int32_t* __restrict__ npath) {
+  stage_dm_tables();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sub = t & (PATH_LANES - 1);
+  const int row = t / PATH_LANES;
+  const int y = row < f.h ? row : f.h - 1; // surplus octets repeat the last row (every lane must reach the shuffles)
+  const bool writer = sub == 0 && row < f.h;
+  const bool sph = f.earth.spherical != 0;
+  const double radius = f.earth.shape_radius;
+  const bool straight = f.p.straight_rays != 0;
+  const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+  const double alt = *f.alt;
+  const OctetRK4<CUBIC> rk4{*f.atm, sub, (int)(threadIdx.x & 63 & ~(PATH_LANES - 1))};
+  Stepper s;
+  stepper_init(s, sph, radius, alt, dm_to_radians(frame_row_elev(f, y)));
+  size_t base = (size_t)y * f.n_path_cap;
+  if (writer) {
+    pelev[base] = alt;
+    plen[base] = 0.0;
+  }
+  int n = 1;
+  double px = 0.0, ph = alt, path_length = 0.0;
+  // utils.rs:159-171: push, then stop once the PREVIOUS state is beyond max_distance or below -1000 m.
+  // The loop bound is wave-uniform; an octet that has finished keeps stepping without storing, so that every lane of
+  // the wavefront takes part in every shuffle.
+  bool done = false;
+  int n_final = 0;
+  for (int i = 1; i < f.n_path_cap; i++) {
+    RayState st = rk4.next(s, sph, radius, straight, step);
+    path_length += calc_dist(sph, radius, px, ph, st.x, st.h);
+    if (!done) {
+      if (writer) {
+        pelev[base + n] = st.h;
+        plen[base + n] = path_length;
+      }
+      n++;
+      if (px > max_dist || ph < -1000.0) {
+        done = true;
+        n_final = n;
+      }
+    }
+    px = st.x;
+    ph = st.h;
+    if (__all(done)) break;
+  }
+  if (!done) n_final = n;
+  if (writer) npath[y] = n_final;
+}
+
+void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream) {
+  if (f.atm_cubic)
+    hipLaunchKernelGGL((k_fast_paths<true>), dim3(cdiv((size_t)f.h * PATH_LANES, 64)), dim3(64), 0, stream, f, ws.pelev, ws.plen, ws.npath);
+  else
+    hipLaunchKernelGGL((k_fast_paths<false>), dim3(cdiv((size_t)f.h * PATH_LANES, 64)), dim3(64), 0, stream, f, ws.pelev, ws.plen, ws.npath);
+}
+
+} // namespace atmrt

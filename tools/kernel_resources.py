@@ -6,7 +6,7 @@ import sys
 import os
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-units = [a for a in sys.argv[1:] if a.endswith(".hip")] or ["atmrt_kernels.hip", "atmrt_march_linear.hip"]
+units = [a for a in sys.argv[1:] if a.endswith(".hip")] or ["atmrt_kernels.hip", "atmrt_paths.hip", "atmrt_march_linear.hip"]
 flags = [a for a in sys.argv[1:] if not a.endswith(".hip")]
 out = ""
 for unit in units:

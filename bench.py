@@ -196,7 +196,7 @@ def main():
                "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
                "all_kernels": {per_kernel[k][0]: {"ms": mean(k), "algorithmic_GBps": per_kernel[k][1] / (mean(k) * 1e-3) / 1e9}
                                for k in keys if mean(k) > 0}}
-        sq_file = os.path.join(ROOT, "profiles", "r01", "sq_counters_v4.json")
+        sq_file = os.path.join(ROOT, "profiles", "r01", "sq_counters_v5.json")
         if os.path.exists(sq_file):
             # the compute side of the roofline, from the committed rocprofv3 SQ-counter passes of this command: fraction of
             # cycles the SIMDs' VALU pipes are busy (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles) and active lanes
@@ -204,8 +204,8 @@ def main():
                 if kernel in name:
                     out["valu"] = {"busy_frac": v["valu_busy_frac"], "lane_utilisation": v["lane_utilisation"],
                                    "valu_lane_instructions_per_ray_step": v.get("valu_lane_instructions_per_ray_step"),
-                                   "source": "profiles/r01/sq_counters_v4.json",
-                                   "note": "k_rect_march is FP64-issue bound (12 n(h) evaluations with pow + 78 divisions per RK4 step), not HBM bound"}
+                                   "source": "profiles/r01/sq_counters_v5.json",
+                                   "note": "k_rect_march is FP64-issue bound (12 n(h) evaluations per RK4 step, each a pow and a Ciddor compressibility term), not HBM bound"}
         return out
 
     elapsed, marched, phase = timed(args.generator, args.steps, args.warmup)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from atm_raytracer_amd import synth
-from util import assert_bitexact, assert_close, run_gpu, run_oracle
+from util import bits, assert_bitexact, assert_close, run_gpu, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -135,6 +135,30 @@ def test_full_size_properties(gpu_ctx):
     for k in ("hit_count", "lat", "lon", "distance", "elevation"):
         assert np.array_equal(a[k], b[k])
     assert a["ray_steps"] == b["ray_steps"] > 0
+
+
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast", "InterpolatingRectilinear"])
+def test_full_size_column_samples_match_oracle(gpu_ctx, oracle_det, generator):
+    """BASELINE headline size, all three generators: the oracle computes three 2-column shards of the SAME 4096x2048 frame
+    (left edge, an interior pair, right edge: 12,288 full-length rays) and the GPU's full frame must hold exactly those bits
+    in those columns — the full-size run checked against the oracle, not only against itself."""
+    cfg, tiles = synth.scene("headline", generator=generator)
+    full = run_gpu(gpu_ctx, cfg, tiles)
+    assert full["hit_count"].shape == (2048, 4096)
+    for c0 in (0, 1777, 4094):
+        shard = synth.scene("headline", generator=generator)[0]
+        shard.params.col_begin, shard.params.col_end = c0, c0 + 2
+        want = run_oracle(oracle_det, shard, tiles)
+        assert want["hit_count"].shape == (2048, 2)
+        for k in ("azimuth", "elevation_angle", "hit_count"):
+            assert np.array_equal(bits(full[k][:, c0:c0 + 2]), bits(want[k])), (k, c0)
+        # trace points of the shard's pixels, gathered from the full frame's packed list (opaque terrain: <= 1 per pixel)
+        sel = full["hit_count"][:, c0:c0 + 2] > 0
+        off = full["hit_offset"][:, c0:c0 + 2][sel].astype(np.int64)
+        woff = want["hit_offset"][want["hit_count"] > 0].astype(np.int64)
+        assert off.size == woff.size > 0
+        for k in ("lat", "lon", "distance", "elevation", "path_length", "normal"):
+            assert np.array_equal(bits(full[k][off]), bits(want[k][woff])), (k, c0)
 
 
 def _object_scene(generator, w, h, alpha=1.0, **kw):

@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9  # lane-instructions/s
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TF = 78.6   # vendor-published FP64 vector peak, secondary figure
 
@@ -202,8 +203,14 @@ def main():
             # cycles the SIMDs' VALU pipes are busy (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles) and active lanes
             for name, v in json.load(open(sq_file)).items():
                 if kernel in name:
+                    ipr = v.get("valu_lane_instructions_per_ray_step")
                     out["valu"] = {"busy_frac": v["valu_busy_frac"], "lane_utilisation": v["lane_utilisation"],
-                                   "valu_lane_instructions_per_ray_step": v.get("valu_lane_instructions_per_ray_step"),
+                                   "valu_lane_instructions_per_ray_step": ipr,
+                                   # live rate of this run against the FP64 issue peak (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz =
+                                   # 3.93e13 lane-instructions/s, i.e. the 78.6 TFLOP/s FP64 vector peak counted in FMAs)
+                                   "lane_instructions_per_s": (ipr * steps_per_launch / (ms * 1e-3)) if ipr else None,
+                                   "fp64_issue_peak_per_s": FP64_ISSUE_PEAK,
+                                   "frac_of_fp64_issue_peak": (ipr * steps_per_launch / (ms * 1e-3) / FP64_ISSUE_PEAK) if ipr else None,
                                    "source": "profiles/r01/sq_counters_v5.json",
                                    "note": "k_rect_march is FP64-issue bound (12 n(h) evaluations per RK4 step, each a pow and a Ciddor compressibility term), not HBM bound"}
         return out

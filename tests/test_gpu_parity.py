@@ -5,6 +5,8 @@ within 1e-4 relative.  Against the deterministic-math oracle the HIP path is in 
 in every f64 field, which is what these tests assert; against the libm oracle (the flavour that
 shares no numerics with the product) the north-star tolerance is asserted.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -217,11 +219,13 @@ EARTHS = ["SimpleSphere", {"Spherical": {"radius": 6371000.0}}, {"Spherical": {"
           {"ObserverAe": {"proj_radius": 6371000.0}}, "SimpleObserverAe"]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ATMRT_RANDOM_SEEDS", "36"))))
 def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     """Seeded random sweep over the parameter space (earth model, direction incl. the 0/360 wrap, tilt, field of view, observer
     altitude kind, non-integer steps whose accumulated distances round, straight / refracted, opaque / translucent, generator,
-    wavelength): every f64 field and every hit decision must match the oracle bit for bit."""
+    wavelength, and — for a third of the seeds — a random atmosphere: 1-4 Linear layers with lapse, isothermal and inversion
+    gradients, or a Spline temperature profile): every f64 field and every hit decision must match the oracle bit for bit.
+    ATMRT_RANDOM_SEEDS widens the sweep (400 seeds were run once when the division/exp/log sequences changed)."""
     rng = np.random.default_rng(1000 + seed)
     gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
     w, h = int(rng.integers(3, 70)), int(rng.integers(2, 40))
@@ -240,6 +244,22 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
         "scene": {"terrain_alpha": float(rng.choice([1.0, 1.0, 0.5, 0.05]))},
         "output": {"width": w, "height": h, "generator": gen},
     }
+    if seed % 3 == 1 or seed >= 24:
+        ra = np.random.default_rng(7000 + seed)
+        if ra.uniform() < 0.3:
+            knots = np.sort(ra.uniform(-500.0, 30_000.0, int(ra.integers(3, 7))))
+            knots[0] = -500.0
+            temps = 288.0 - 0.0055 * knots + ra.uniform(-6.0, 6.0, knots.size)
+            first = {"Spline": {"boundary_condition": "Natural", "points": [[float(a), float(t)] for a, t in zip(knots, temps)]}}
+            doc["atmosphere"] = {"pressure": {"altitude": 0.0, "pressure": float(ra.uniform(950.0, 1040.0)) * 100.0},
+                                 "first_temperature_function": first}
+        else:
+            grads = [float(ra.choice([-0.0065, -0.0098, 0.0, 0.003, -0.002, float(ra.uniform(-0.009, 0.004))])) for _ in range(int(ra.integers(1, 5)))]
+            alts = np.sort(ra.uniform(300.0, 25_000.0, len(grads) - 1))
+            doc["atmosphere"] = {"pressure": {"altitude": float(ra.uniform(0.0, 500.0)), "pressure": float(ra.uniform(950.0, 1040.0)) * 100.0},
+                                 "temperature_fixed_point": {"altitude": float(ra.uniform(0.0, 2000.0)), "temperature": float(ra.uniform(255.0, 305.0))},
+                                 "first_temperature_function": {"Linear": {"gradient": grads[0]}},
+                                 "next_functions": [{"altitude": float(a), "function": {"Linear": {"gradient": g}}} for a, g in zip(alts, grads[1:])]}
     from atm_raytracer_amd import config
     cfg = config.Config.from_dict(doc)
     tiles = synth.synth_tiles([46], [8], level=301)

@@ -71,6 +71,9 @@ struct PackedHits {
 };
 
 // Scratch owned by the context, sized for the current frame.
+// crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
+constexpr int RECT_SLOTS = 4;
+
 struct Workspace {
   double* alt;            // [1]
   DirCalc* colcalc;       // [wl]   Fast: per-column DirectionalCalc
@@ -85,6 +88,12 @@ struct Workspace {
   uint32_t* list_step;    // multi-hit: per trace point, the step index and ...
   uint32_t* list_pixel;   // ... its pixel
   double* rect_rec;       // Rectilinear: [4][n] ray elevation / path length at the two bracketing samples
+  // Rectilinear with translucent terrain: the counting march keeps the first RECT_SLOTS crossings of every pixel, so that only
+  // pixels with more crossings are marched a second time
+  uint32_t* slot_step;    // [RECT_SLOTS][h][wl]
+  double* slot_rec;       // [4][RECT_SLOTS][h][wl]
+  uint32_t* overflow;     // pixels with more than RECT_SLOTS crossings
+  uint64_t n_overflow;    // their number (host copy of counters[3] after the counting march)
   // scenes with objects (Fast): geodesic point of every sample and the objects close to it (utils.rs:74-80)
   double* plat;           // [n_t][wl]
   double* plon;           // [n_t][wl]

@@ -32,11 +32,14 @@ template <int MODE, int CALC, bool CUBIC>
 __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
-                                                    unsigned long long* __restrict__ counters) {
+                                                    unsigned long long* __restrict__ counters,
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list) {
   stage_dm_tables();
   const size_t plane = (size_t)f.wl * f.h;
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < plane;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // MODE 2 may be restricted to a list of pixels (those whose crossings did not fit the slots of the counting march)
+  const bool live = pixel_list ? tid < n_list : tid < plane;
+  const size_t p = pixel_list ? (live ? pixel_list[tid] : 0) : tid;
   unsigned long long steps = 0;
   if (live) {
     const Earth e = earth_for<CALC>(f);
@@ -79,6 +82,15 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
             rec.pl0[p] = pl0;
             rec.re1[p] = sh;
             rec.pl1[p] = path_length;
+          } else if (MODE == 1) {
+            if (count < (unsigned)RECT_SLOTS) { // slot arrays come in through list_step / rec, slot-major
+              const size_t q = (size_t)count * plane + p;
+              list_step[q] = (uint32_t)(i - 1);
+              rec.re0[q] = re0;
+              rec.pl0[q] = pl0;
+              rec.re1[q] = sh;
+              rec.pl1[q] = path_length;
+            }
           } else if (MODE == 2) {
             list_step[k] = (uint32_t)(i - 1);
             list_pixel[k] = (uint32_t)p;
@@ -102,6 +114,7 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
       out.hit_count[p] = count;
     }
     if (MODE == 0) hit_step[p] = first;
+    if (MODE == 1 && count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
   }
   if (MODE != 2) {
     steps = wave_sum(steps);
@@ -314,28 +327,64 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<0, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
                                                           f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
                                                           (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                          (unsigned long long*)ws.counters));
+                                                          (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u));
     (void)hipEventRecord(ev_marched, stream);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
                                                           f, ws.hit_step, rec, out));
   } else {
+    RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<1, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
-                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                          (unsigned long long*)ws.counters));
+                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, slots,
+                                                          ws.slot_step, (uint32_t*)nullptr,
+                                                          (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u));
     (void)hipEventRecord(ev_marched, stream);
   }
 }
 
-// terrain_alpha < 1, Rectilinear: second march lists every crossing, then one thread per trace point
+// The crossings the counting march kept in its slots, moved to their places in the pixel-ordered list; pixels with more
+// crossings than slots are collected for a second march (counters[3] was reset by the host and hands out list positions).
+static __global__ __launch_bounds__(256) void k_rect_gather_slots(Frame f, const uint32_t* __restrict__ hit_count,
+                                                           const uint64_t* __restrict__ hit_offset,
+                                                           const uint32_t* __restrict__ slot_step, RectRec slots,
+                                                           uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                           RectRec rec, uint32_t* __restrict__ overflow,
+                                                           unsigned long long* __restrict__ counters) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const uint32_t n = hit_count[p];
+  if (n > (uint32_t)RECT_SLOTS) {
+    overflow[atomicAdd(&counters[3], 1ull)] = (uint32_t)p;
+    return;
+  }
+  const uint64_t k = hit_offset[p];
+  for (uint32_t j = 0; j < n; j++) {
+    const size_t q = (size_t)j * plane + p;
+    list_step[k + j] = slot_step[q];
+    list_pixel[k + j] = (uint32_t)p;
+    rec.re0[k + j] = slots.re0[q];
+    rec.pl0[k + j] = slots.pl0[q];
+    rec.re1[k + j] = slots.re1[q];
+    rec.pl1[k + j] = slots.pl1[q];
+  }
+}
+
+// terrain_alpha < 1, Rectilinear: gather the recorded crossings, march the overflow pixels again listing every crossing,
+// then one thread per trace point
 template <bool CUBIC>
 void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                          hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<2, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f,
-                                                        dense, ws.hit_step, ws.hit_offset, rec, ws.list_step,
-                                                        ws.list_pixel, (unsigned long long*)ws.counters));
+  RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
+  hipLaunchKernelGGL(k_rect_gather_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count, ws.hit_offset,
+                     ws.slot_step, slots, ws.list_step, ws.list_pixel, rec, ws.overflow, (unsigned long long*)ws.counters);
+  if (ws.n_overflow) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<2, CALC, CUBIC>), dim3(cdiv((size_t)ws.n_overflow, 256)), dim3(256), 0,
+                                                          stream, f, dense, ws.hit_step, ws.hit_offset, rec, ws.list_step, ws.list_pixel,
+                                                          (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow,
+                                                          (uint32_t)ws.n_overflow));
+  }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                           stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));

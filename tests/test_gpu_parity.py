@@ -73,6 +73,20 @@ def test_translucent_terrain_multi_hit(gpu_ctx, oracle_det, generator):
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
 
 
+def test_translucent_rectilinear_more_crossings_than_slots(gpu_ctx, oracle_det):
+    """Rectilinear, terrain_alpha < 1: the counting march records the first 4 crossings of a pixel in slots and only pixels with
+    more are marched again (k_rect_gather_slots + the pixel-list form of k_rect_march).  A narrow grazing view of the headline
+    terrain has both kinds of pixel (up to ~10 crossings), also inside one wavefront."""
+    cfg, tiles = synth.scene("headline", 72, 72, generator="Rectilinear", terrain_alpha=0.3, fov=20.0, tilt=-1.0)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    over = int((got["hit_count"] > 4).sum())
+    assert over > 0 and int((got["hit_count"] > 0).sum()) > over, (over, int(got["hit_count"].max()))
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+    # a frame whose crossings all fit the slots right after one that overflowed (the overflow list must not leak)
+    cfg2, tiles2 = synth.scene("S2", 48, 24, generator="Rectilinear", terrain_alpha=0.5, tilt=-4.0)
+    assert_bitexact(run_gpu(gpu_ctx, cfg2, tiles2), run_oracle(oracle_det, cfg2, tiles2))
+
+
 def test_three_by_three_tiles_and_shards(gpu_ctx, oracle_det):
     """BASELINE config 3 layout (3x3 tiles, 120 deg fov) at reduced size, computed as two column shards."""
     cfg, tiles = synth.scene("S3", 128, 64, step=200.0)

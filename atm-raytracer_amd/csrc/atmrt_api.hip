@@ -95,7 +95,7 @@ struct atmrt_ctx {
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
-      d_overflow;
+      d_overflow, d_slot_pixel, d_slot_packed;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -267,7 +267,7 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
                     &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
-                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow})
+                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed})
     b->release();
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -578,6 +578,9 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   return ATMRT_OK;
 }
 
+static PackedHits carve_packed(void* base, size_t n);
+static size_t packed_bytes(size_t n);
+
 static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   size_t npx = (size_t)f.wl * f.h;
   HIP_TRY(c, c->d_counters.reserve(4 * sizeof(uint64_t)));
@@ -606,10 +609,17 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   }
   if (f.p.generator == ATMRT_GEN_RECTILINEAR) HIP_TRY(c, c->d_rect_rec.reserve(4 * npx * sizeof(double)));
   ws->rect_rec = c->d_rect_rec.as<double>();
-  if (f.p.generator == ATMRT_GEN_RECTILINEAR && !f.opaque && f.n_objects == 0) { // slots of the counting march
+  ws->slot_packed = PackedHits{};
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR && (!f.opaque || f.n_objects > 0)) { // slots of the counting march / trace
     HIP_TRY(c, c->d_slot_step.reserve((size_t)RECT_SLOTS * npx * sizeof(uint32_t)));
     HIP_TRY(c, c->d_slot_rec.reserve(4 * (size_t)RECT_SLOTS * npx * sizeof(double)));
+    if (f.n_objects > 0) {
+      HIP_TRY(c, c->d_slot_pixel.reserve((size_t)RECT_SLOTS * npx * sizeof(uint32_t)));
+      HIP_TRY(c, c->d_slot_packed.reserve(packed_bytes((size_t)RECT_SLOTS * npx)));
+      ws->slot_packed = carve_packed(c->d_slot_packed.ptr, (size_t)RECT_SLOTS * npx);
+    }
   }
+  ws->slot_pixel = c->d_slot_pixel.as<uint32_t>();
   ws->slot_step = c->d_slot_step.as<uint32_t>();
   ws->slot_rec = c->d_slot_rec.as<double>();
   ws->overflow = c->d_overflow.as<uint32_t>();
@@ -732,13 +742,15 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
         HIP_TRY(c, c->d_rect_rec.reserve(4 * (n_hits + 1) * sizeof(double)));
         ws.rect_rec = c->d_rect_rec.as<double>();
       }
-      if (general) {
-        launch_trace_fill(f, ws, n_hits, dense, packed, s);
-      } else if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
-        ws.n_overflow = counters[3]; // pixels whose crossings did not fit the slots: the only ones marched a second time
+      if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
+        ws.n_overflow = counters[3]; // pixels whose points did not fit the slots: the only ones marched a second time
         HIP_TRY(c, c->d_overflow.reserve((ws.n_overflow + 1) * sizeof(uint32_t)));
         ws.overflow = c->d_overflow.as<uint32_t>();
         HIP_TRY(c, hipMemsetAsync(ws.counters + 3, 0, sizeof(uint64_t), s)); // now the gather kernel's list cursor
+      }
+      if (general) {
+        launch_trace_fill(f, ws, n_hits, dense, packed, s);
+      } else if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
         launch_multi_fill(f, ws, n_hits, dense, packed, s);
       } else {
         launch_multi_fill_fast(f, ws, n_hits, dense, packed, s);

@@ -93,6 +93,8 @@ struct Workspace {
   uint32_t* slot_step;    // [RECT_SLOTS][h][wl]
   double* slot_rec;       // [4][RECT_SLOTS][h][wl]
   uint32_t* overflow;     // pixels with more than RECT_SLOTS crossings
+  uint32_t* slot_pixel;   // scenes with objects: [h][wl][RECT_SLOTS] (written by step_emit, not read)
+  PackedHits slot_packed; // scenes with objects: trace points of the slots, entry p * RECT_SLOTS + j
   uint64_t n_overflow;    // their number (host copy of counters[3] after the counting march)
   // scenes with objects (Fast): geodesic point of every sample and the objects close to it (utils.rs:74-80)
   double* plat;           // [n_t][wl]

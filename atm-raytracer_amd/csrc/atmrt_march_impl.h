@@ -219,12 +219,18 @@ template <bool FILL, int CALC, bool CUBIC>
 __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
                                                     PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
                                                     uint32_t* __restrict__ list_pixel,
-                                                    unsigned long long* __restrict__ counters) {
+                                                    unsigned long long* __restrict__ counters,
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list) {
+  // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
+  // (packed / rec / list_step then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its place in
+  // the pixel-ordered list, for all pixels or for the listed ones (those that did not fit their slots).
   stage_dm_tables();
   const size_t plane = (size_t)f.wl * f.h;
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = pixel_list ? tid < n_list : tid < plane;
+  const size_t p = pixel_list ? (live ? pixel_list[tid] : 0) : tid;
   unsigned long long steps = 0;
-  if (p < plane) {
+  if (live) {
     const Earth e = earth_for<CALC>(f);
     const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
     const bool sph = e.spherical != 0;
@@ -285,7 +291,8 @@ __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, co
             step_object(hits, f, idx, pos1, pos2, counters);
           }
         }
-        if (FILL && hits.n) {
+        if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;
+        if (hits.n && (FILL || count + (unsigned)hits.n <= (unsigned)RECT_SLOTS)) {
           uint64_t k0 = k;
           step_emit(hits, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx,
                     path_length);
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, co
       out.azimuth[p] = dm_to_degrees(direction);
       out.elevation_angle[p] = dm_to_degrees(elevation);
       out.hit_count[p] = count;
+      if (count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
     }
   }
   if (!FILL) {
@@ -395,12 +403,53 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
 
 template <bool CUBIC>
 void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
-  PackedHits none = {};
   size_t n = (size_t)f.wl * f.h;
-  RectRec rec = {};
+  RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
-                                                        (const uint64_t*)nullptr, none, rec, (uint32_t*)nullptr,
-                                                        (uint32_t*)nullptr, (unsigned long long*)ws.counters));
+                                                        (const uint64_t*)nullptr, ws.slot_packed, slots, ws.slot_step,
+                                                        ws.slot_pixel, (unsigned long long*)ws.counters,
+                                                        (const uint32_t*)nullptr, 0u));
+}
+
+// Trace points kept in the slot arena by the counting pass of k_rect_trace, moved to their places in the pixel-ordered list
+// (object points are complete; terrain points carry the record k_rect_finalize_list needs); overflow pixels are listed.
+static __global__ __launch_bounds__(256) void k_rect_gather_trace_slots(Frame f, const uint32_t* __restrict__ hit_count,
+                                                                        const uint64_t* __restrict__ hit_offset,
+                                                                        const uint32_t* __restrict__ slot_step, RectRec slots,
+                                                                        PackedHits sp, uint32_t* __restrict__ list_step,
+                                                                        uint32_t* __restrict__ list_pixel, RectRec rec,
+                                                                        PackedHits packed, uint32_t* __restrict__ overflow,
+                                                                        unsigned long long* __restrict__ counters) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const uint32_t n = hit_count[p];
+  if (n > (uint32_t)RECT_SLOTS) {
+    overflow[atomicAdd(&counters[3], 1ull)] = (uint32_t)p;
+    return;
+  }
+  const uint64_t k0 = hit_offset[p];
+  for (uint32_t j = 0; j < n; j++) {
+    const size_t q = p * RECT_SLOTS + j;
+    const uint64_t k = k0 + j;
+    list_step[k] = slot_step[q];
+    list_pixel[k] = (uint32_t)p;
+    rec.re0[k] = slots.re0[q];
+    rec.pl0[k] = slots.pl0[q];
+    rec.re1[k] = slots.re1[q];
+    rec.pl1[k] = slots.pl1[q];
+    const uint32_t tag = sp.color_tag[q];
+    packed.color_tag[k] = tag;
+    if (tag != ATMRT_COLOR_TERRAIN) { // terrain points are completed by k_rect_finalize_list
+      packed.lat[k] = sp.lat[q];
+      packed.lon[k] = sp.lon[q];
+      packed.distance[k] = sp.distance[q];
+      packed.elevation[k] = sp.elevation[q];
+      packed.path_length[k] = sp.path_length[q];
+      for (int c = 0; c < 3; c++) packed.normal[3 * k + c] = sp.normal[3 * q + c];
+      for (int c = 0; c < 4; c++) packed.rgba[4 * k + c] = sp.rgba[4 * q + c];
+    }
+  }
 }
 
 template <bool CUBIC>
@@ -408,9 +457,16 @@ void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, co
                               hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, dense, ws.hit_offset,
-                                                        packed, rec, ws.list_step, ws.list_pixel,
-                                                        (unsigned long long*)ws.counters));
+  RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
+  hipLaunchKernelGGL(k_rect_gather_trace_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count,
+                     ws.hit_offset, ws.slot_step, slots, ws.slot_packed, ws.list_step, ws.list_pixel, rec, packed, ws.overflow,
+                     (unsigned long long*)ws.counters);
+  if (ws.n_overflow) {
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC, CUBIC>), dim3(cdiv((size_t)ws.n_overflow, 256)), dim3(256), 0,
+                                                          stream, f, dense, ws.hit_offset, packed, rec, ws.list_step, ws.list_pixel,
+                                                          (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow,
+                                                          (uint32_t)ws.n_overflow));
+  }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                           stream, f, n_hits, ws.list_step, ws.list_pixel, rec, packed));

@@ -225,6 +225,9 @@ def test_objects_in_a_line_overflow_the_candidate_list(gpu_ctx, oracle_det):
     synth.add_objects(cfg, n_cyl=40, n_bill=0, dist=(500.0, 25_000.0), spread_deg=0.02, radius=(30.0, 60.0), height=(400.0, 900.0))
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert (got["color_tag"] == 1).sum() > 20
+    # translucent objects behind one another: pixels with more trace points than the 4 slots of the counting pass AND pixels
+    # within them, i.e. both the slot gather and the listed re-trace of k_rect_trace run
+    assert (got["hit_count"] > 4).any() and ((got["hit_count"] > 0) & (got["hit_count"] <= 4)).any(), got["hit_count"].max()
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
 
 

@@ -88,8 +88,15 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # ATMRT_BENCH_BACKEND=gloo is a rehearsal aid for a one-GPU box (several ranks share cuda:0 and the planes are gathered
+        # through host memory); the driver's multi-GPU runs use the default, RCCL
+        backend = os.environ.get("ATMRT_BENCH_BACKEND", "nccl")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the ray-marching library has no CPU path")
+        if backend == "gloo":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-marching library has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -132,7 +139,12 @@ def main():
             steps, _ms = gen.generate_device(pod)  # returns after the library's stream has drained
             if distributed:
                 for k, v in local.items():  # one RCCL all-gather per result plane
-                    dist.all_gather_into_tensor(gathered[k], v)
+                    if backend == "gloo":
+                        host = torch.empty(gathered[k].shape, dtype=v.dtype)
+                        dist.all_gather_into_tensor(host, v.cpu())
+                        gathered[k].copy_(host)
+                    else:
+                        dist.all_gather_into_tensor(gathered[k], v)
             return steps, gen.last_timings()
         return step
 
@@ -252,7 +264,9 @@ def main():
         from atm_raytracer_amd.sharding import assemble
         full = assemble(gathered["distance"].view((world,) + tuple(local["distance"].shape)))
         ok = full.shape == (H, W) and torch.equal(full[:, c0:c1].nan_to_num(-1.0), local["distance"].nan_to_num(-1.0))
-        log(f"gathered image check: shape {tuple(full.shape)}, rank-0 shard matches: {bool(ok)}")
+        hits = assemble(gathered["hit_count"].view((world,) + tuple(local["hit_count"].shape)))
+        log(f"gathered image check: shape {tuple(full.shape)}, rank-0 shard matches: {bool(ok)}, hit pixels per rank shard: "
+            f"{[int((hits[:, g * wl:(g + 1) * wl] > 0).sum()) for g in range(world)]}")
     ctx.close()
     if distributed:
         dist.destroy_process_group()

@@ -937,20 +937,62 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
 // ---------------------------------------------------------------------------------------------
 // the path
 // ---------------------------------------------------------------------------------------------
+// Host memory of atmrt_result_t: ONE page-locked block per result (device-to-host copies run at PCIe speed into it; through
+// pageable memory the 0.7 GB of a headline frame cost 55 ms, eight times the Fast generator's device time), carved into the
+// arrays with 256-byte alignment.  Pinning is slow, so freed blocks are kept (at most two, process-wide) and reused by later
+// frames of a similar size.  If pinned memory cannot be had the block is ordinary malloc memory.
+namespace {
+struct HostBlocks {
+  std::mutex m;
+  struct Blk {
+    void* p;
+    size_t cap;
+    bool pinned;
+  };
+  std::vector<Blk> live, spare;
+  void* take(size_t bytes) {
+    std::lock_guard<std::mutex> g(m);
+    for (size_t i = 0; i < spare.size(); i++)
+      if (spare[i].cap >= bytes && spare[i].cap / 2 <= bytes) {
+        Blk b = spare[i];
+        spare.erase(spare.begin() + (long)i);
+        live.push_back(b);
+        return b.p;
+      }
+    Blk b{nullptr, bytes + bytes / 16, true};
+    if (hipHostMalloc(&b.p, b.cap, hipHostMallocDefault) != hipSuccess || !b.p) {
+      (void)hipGetLastError();
+      b = Blk{malloc(bytes), bytes, false};
+      if (!b.p) return nullptr;
+    }
+    live.push_back(b);
+    return b.p;
+  }
+  void give(void* p) {
+    std::lock_guard<std::mutex> g(m);
+    for (size_t i = 0; i < live.size(); i++)
+      if (live[i].p == p) {
+        Blk b = live[i];
+        live.erase(live.begin() + (long)i);
+        if (!b.pinned) {
+          free(b.p);
+          return;
+        }
+        spare.push_back(b);
+        if (spare.size() > 2) {
+          (void)hipHostFree(spare.front().p);
+          spare.erase(spare.begin());
+        }
+        return;
+      }
+  }
+};
+HostBlocks g_host_blocks;
+} // namespace
+
 extern "C" void atmrt_result_free(atmrt_result_t* r) {
   if (!r) return;
-  free(r->azimuth);
-  free(r->elevation_angle);
-  free(r->hit_count);
-  free(r->hit_offset);
-  free(r->lat);
-  free(r->lon);
-  free(r->distance);
-  free(r->elevation);
-  free(r->path_length);
-  free(r->normal);
-  free(r->color_tag);
-  free(r->rgba);
+  if (r->azimuth) g_host_blocks.give(r->azimuth); // the first array is the base of the block
   memset(r, 0, sizeof *r);
 }
 
@@ -977,37 +1019,48 @@ extern "C" int atmrt_generate(atmrt_ctx* c, atmrt_result_t* out) {
   out->ray_steps = steps;
   out->device_ms = ms;
   size_t nh = n_hits ? n_hits : 1;
-  out->azimuth = (double*)malloc(npx * 8);
-  out->elevation_angle = (double*)malloc(npx * 8);
-  out->hit_count = (uint32_t*)malloc(npx * 4);
-  out->hit_offset = (uint64_t*)malloc(npx * 8);
-  out->lat = (double*)malloc(nh * 8);
-  out->lon = (double*)malloc(nh * 8);
-  out->distance = (double*)malloc(nh * 8);
-  out->elevation = (double*)malloc(nh * 8);
-  out->path_length = (double*)malloc(nh * 8);
-  out->normal = (double*)malloc(nh * 24);
-  out->color_tag = (uint32_t*)malloc(nh * 4);
-  out->rgba = (double*)malloc(nh * 32);
-  if (!out->azimuth || !out->elevation_angle || !out->hit_count || !out->hit_offset || !out->lat || !out->lon ||
-      !out->distance || !out->elevation || !out->path_length || !out->normal || !out->color_tag || !out->rgba) {
-    atmrt_result_free(out);
-    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "out of host memory for %zu pixels / %llu hits", npx,
-                   (unsigned long long)n_hits);
-  }
-  HIP_TRY(c, hipMemcpy(out->azimuth, dense.azimuth, npx * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(out->elevation_angle, dense.elevation_angle, npx * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(out->hit_count, dense.hit_count, npx * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(out->hit_offset, ws.hit_offset, npx * 8, hipMemcpyDeviceToHost));
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t total = 3 * pad(npx * 8) + pad(npx * 4) + 5 * pad(nh * 8) + pad(nh * 24) + pad(nh * 4) + pad(nh * 32);
+  char* base = static_cast<char*>(g_host_blocks.take(total));
+  if (!base)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "out of host memory for %zu pixels / %llu hits", npx, (unsigned long long)n_hits);
+  auto carve = [&](size_t bytes) {
+    void* r = base;
+    base += pad(bytes);
+    return r;
+  };
+  out->azimuth = (double*)carve(npx * 8); // first: atmrt_result_free returns the block by this pointer
+  out->elevation_angle = (double*)carve(npx * 8);
+  out->hit_offset = (uint64_t*)carve(npx * 8);
+  out->hit_count = (uint32_t*)carve(npx * 4);
+  out->lat = (double*)carve(nh * 8);
+  out->lon = (double*)carve(nh * 8);
+  out->distance = (double*)carve(nh * 8);
+  out->elevation = (double*)carve(nh * 8);
+  out->path_length = (double*)carve(nh * 8);
+  out->normal = (double*)carve(nh * 24);
+  out->rgba = (double*)carve(nh * 32);
+  out->color_tag = (uint32_t*)carve(nh * 4);
+  hipStream_t s = c->stream;
+  auto d2h = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s); };
+  hipError_t e = d2h(out->azimuth, dense.azimuth, npx * 8);
+  if (e == hipSuccess) e = d2h(out->elevation_angle, dense.elevation_angle, npx * 8);
+  if (e == hipSuccess) e = d2h(out->hit_count, dense.hit_count, npx * 4);
+  if (e == hipSuccess) e = d2h(out->hit_offset, ws.hit_offset, npx * 8);
   if (n_hits) {
-    HIP_TRY(c, hipMemcpy(out->lat, packed.lat, n_hits * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->lon, packed.lon, n_hits * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->distance, packed.distance, n_hits * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->elevation, packed.elevation, n_hits * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->path_length, packed.path_length, n_hits * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->normal, packed.normal, n_hits * 24, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->color_tag, packed.color_tag, n_hits * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(out->rgba, packed.rgba, n_hits * 32, hipMemcpyDeviceToHost));
+    if (e == hipSuccess) e = d2h(out->lat, packed.lat, n_hits * 8);
+    if (e == hipSuccess) e = d2h(out->lon, packed.lon, n_hits * 8);
+    if (e == hipSuccess) e = d2h(out->distance, packed.distance, n_hits * 8);
+    if (e == hipSuccess) e = d2h(out->elevation, packed.elevation, n_hits * 8);
+    if (e == hipSuccess) e = d2h(out->path_length, packed.path_length, n_hits * 8);
+    if (e == hipSuccess) e = d2h(out->normal, packed.normal, n_hits * 24);
+    if (e == hipSuccess) e = d2h(out->color_tag, packed.color_tag, n_hits * 4);
+    if (e == hipSuccess) e = d2h(out->rgba, packed.rgba, n_hits * 32);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    atmrt_result_free(out);
+    return c->fail(ATMRT_ERR_HIP, "copying the result to the host: %s", hipGetErrorString(e));
   }
   return ATMRT_OK;
 }

@@ -222,7 +222,8 @@ int atmrt_objects_set(atmrt_ctx* ctx, const atmrt_object_t* objects, size_t n);
 /* ---- the path ----------------------------------------------------------------------------- */
 /* Generator::generate for the generator named in params (generators/mod.rs:82-84): Fast (fast.rs:22-98), Rectilinear
  * (rectilinear.rs:24-60) or InterpolatingRectilinear (interpolating_rectilinear.rs:110-162), with or without scene objects and
- * for any terrain_alpha.  The result is library-allocated host memory; release with atmrt_result_free. */
+ * for any terrain_alpha.  The result is library-allocated host memory — one page-locked block the arrays point into, so the
+ * device-to-host copy runs at PCIe speed; release it (as a whole) with atmrt_result_free, which keeps the block for the next frame. */
 int atmrt_generate(atmrt_ctx* ctx, atmrt_result_t* out);
 void atmrt_result_free(atmrt_result_t* r);
 /* Same computation, results left in HBM in caller-provided planes; ray_steps/device_ms optional. */

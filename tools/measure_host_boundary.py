@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point (atmrt_generate: device compute + packing + copy of every result array to
+host memory the library allocates), next to the HBM-resident rate bench.py reports.  Headline workload, one GPU.
+Writes one JSON object to stdout; profiles/r01/host_boundary.json is a committed run of it."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from atm_raytracer_amd import _abi, generators, synth  # noqa: E402
+
+
+def main():
+    out = {}
+    ctx = generators.Context(0)
+    cfg, tiles = synth.scene("headline", level=2)
+    terrain = generators.Terrain.from_tiles(tiles, ctx)
+    for name in ("Rectilinear", "Fast"):
+        cfg.params.generator = _abi.GENERATORS[name]
+        gen = generators.make_generator(generators.Params(cfg), terrain)
+        gen._configure()
+        lib, h = ctx.lib, ctx.handle
+        times, nbytes, steps, dev_ms = [], 0, 0, 0.0
+        for it in range(4):
+            res = _abi.Result()
+            t0 = time.perf_counter()
+            ctx.check(lib.atmrt_generate(h, C.byref(res)))
+            dt = time.perf_counter() - t0
+            steps, dev_ms = res.ray_steps, res.device_ms
+            nbytes = res.n_pixels * (8 + 8 + 4 + 8) + res.n_hits * (5 * 8 + 24 + 4 + 32)
+            lib.atmrt_result_free(C.byref(res))
+            if it:
+                times.append(dt)
+        wall = sum(times) / len(times)
+        out[name] = {"wall_ms": wall * 1e3, "device_ms": dev_ms, "result_bytes": int(nbytes), "ray_steps": int(steps),
+                     "ray_steps_per_s_pcie_inclusive": steps / wall, "ray_steps_per_s_device": steps / (dev_ms * 1e-3)}
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

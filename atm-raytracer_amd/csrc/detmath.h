@@ -5,12 +5,16 @@
  * those functions differently in the last bit, and a last-bit difference in a terrain or ray
  * elevation can flip the strict sign test of the tracer (utils.rs:222).  To make hit/miss and
  * step indices bit-identical between the CPU checker and the HIP kernels, both sides evaluate
- * the SAME sequence of IEEE-754 binary64 operations (+ - * / sqrt are correctly rounded on x86-64
- * and on gfx950; contraction into FMA is disabled with -ffp-contract=off on both compilers).
+ * the SAME sequence of IEEE-754 binary64 operations (+ - * / sqrt and fma are correctly rounded
+ * on x86-64 and on gfx950; implicit contraction is disabled with -ffp-contract=off on both
+ * compilers, so an FMA happens exactly where DM_FMA is written).
  *
- * The algorithms are the classical published ones (Cody–Waite reduction + minimax polynomial
- * kernels in the style of Sun's fdlibm, K.C. Ng 1993); tests/test_detmath.py bounds every
- * function at <= 2 ulp against glibc and mpmath over the argument ranges the tracer uses.
+ * The algorithms are the classical published ones: Cody–Waite reduction + minimax polynomial
+ * kernels in the style of Sun's fdlibm (K.C. Ng 1993) for sin cos tan atan atan2 asin; table-driven
+ * exp and log after P.T.P. Tang (1989/1990) with the tables of detmath_tables.h.
+ * tests/test_detmath.py bounds every function at <= 1 ulp (tan 2, pow 4) against glibc and mpmath
+ * over the argument ranges the tracer uses.  dm_div / dm_div_r / dm_sqrt_inrange are GPU instruction
+ * sequences that return the bits of the IEEE operation for in-range operands (host: the operation).
  *
  * Plain C99 / C++: include with DM_FN predefined to add __host__ __device__ in HIP code.
  */
@@ -68,7 +72,7 @@ DM_FN double dm_to_degrees(double rad) { return rad * DM_DEG_PER_RAD; }
  * (|exponent| < 500; a may also be +0).  On the host this IS the IEEE division.  On gfx950 the compiler expands `/` into
  * v_div_scale x2, v_rcp, two Newton steps on the reciprocal, q = a r, one residual correction, v_div_fmas, v_div_fixup;
  * for operands in that range the scaling steps multiply by 1 and the fix-up passes the quotient through, so the same
- * sequence without them returns the same bits with 8 instructions instead of 11.  (78 divisions per RK4 step.) */
+ * sequence without them returns the same bits with 8 instructions instead of 11.  (The march executes ~70 divisions per RK4 step.) */
 #if defined(__HIP_DEVICE_COMPILE__)
 DM_FN double dm_div(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);

@@ -131,6 +131,8 @@ def main():
     if distributed:
         gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in local.items()}
 
+    gather_events, gather_ms = [], {}
+
     def make_step(generator_name):
         cfg.params.generator = _abi.GENERATORS[generator_name]
         gen = generators.make_generator(generators.Params(cfg), terrain)
@@ -138,6 +140,9 @@ def main():
         def step():
             steps, _ms = gen.generate_device(pod)  # returns after the library's stream has drained
             if distributed:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                gather_events.append((ev0, ev1))
+                ev0.record()
                 for k, v in local.items():  # one RCCL all-gather per result plane
                     if backend == "gloo":
                         host = torch.empty(gathered[k].shape, dtype=v.dtype)
@@ -145,6 +150,7 @@ def main():
                         gathered[k].copy_(host)
                     else:
                         dist.all_gather_into_tensor(gathered[k], v)
+                ev1.record()
             return steps, gen.last_timings()
         return step
 
@@ -155,6 +161,7 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+        gather_events.clear()
         t0 = time.perf_counter()
         marched, phase = 0, []
         for _ in range(k_steps):
@@ -172,6 +179,10 @@ def main():
             tot = stats[1:].clone()
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             elapsed, marched = float(tmax.item()), float(tot.item())
+            # the exchange step on its own: mean all-gather time per frame, slowest rank
+            g = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in gather_events]))], dtype=torch.float64, device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gather_ms[generator_name] = float(g.item())
         return elapsed, marched, phase
 
     def roofline(generator_name, phase):
@@ -243,6 +254,8 @@ def main():
         "value_per_gpu": marched / elapsed / world,
         "roofline": roofline(args.generator, phase),
     }
+    if distributed:
+        result["all_gather_ms_per_step"] = gather_ms.get(args.generator)  # inside ms_per_step; 11 planes, 88 B per pixel
     if not args.only and args.generator == "Rectilinear":
         # the reference's other two generators on the same workload (secondary lines; `value` above is the per-pixel march)
         e2, m2, ph2 = timed("Fast", args.steps, 1)

@@ -79,6 +79,12 @@ class DevicePlanes(C.Structure):
                 ("normal", C.c_void_p)]
 
 
+class DeviceHits(C.Structure):
+    _fields_ = [("capacity", C.c_uint64), ("hit_offset", C.c_void_p), ("lat", C.c_void_p), ("lon", C.c_void_p), ("distance", C.c_void_p),
+                ("elevation", C.c_void_p), ("path_length", C.c_void_p), ("normal", C.c_void_p), ("color_tag", C.c_void_p),
+                ("rgba", C.c_void_p)]
+
+
 class Coloring(C.Structure):
     _fields_ = [("kind", C.c_int32), ("palette", C.c_int32), ("water_level", C.c_double), ("max_distance", C.c_double),
                 ("ambient_light", C.c_double), ("light_dir", C.c_double * 3), ("has_fog", C.c_int32), ("_pad", C.c_int32),

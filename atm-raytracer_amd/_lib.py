@@ -62,6 +62,7 @@ def load():
         "atmrt_generate": (C.c_int, [vp, C.POINTER(_abi.Result)]),
         "atmrt_result_free": (None, [C.POINTER(_abi.Result)]),
         "atmrt_generate_device": (C.c_int, [vp, C.POINTER(_abi.DevicePlanes), C.POINTER(C.c_uint64), pd]),
+        "atmrt_last_hits_device": (C.c_int, [vp, C.POINTER(_abi.DeviceHits), C.POINTER(C.c_uint64)]),
         "atmrt_last_timings": (C.c_int, [vp, C.POINTER(_abi.Timings)]),
         "atmrt_coloring_from_conf": (C.c_int, [C.POINTER(_abi.Params), i32, dbl, dbl, dbl, dbl, i32, i32, dbl, C.POINTER(_abi.Coloring)]),
         "atmrt_draw_image": (C.c_int, [vp, C.POINTER(_abi.Coloring), vp]),
@@ -83,6 +84,6 @@ def load():
 EXPORTED = ["atmrt_abi_version", "atmrt_ctx_create", "atmrt_ctx_destroy", "atmrt_last_error", "atmrt_terrain_load_dir",
             "atmrt_terrain_add_tile", "atmrt_terrain_clear", "atmrt_terrain_get_elev", "atmrt_params_default",
             "atmrt_atmosphere_us76", "atmrt_set_params", "atmrt_set_atmosphere", "atmrt_objects_set", "atmrt_generate",
-            "atmrt_result_free", "atmrt_generate_device", "atmrt_last_timings", "atmrt_coloring_from_conf", "atmrt_draw_image",
+            "atmrt_result_free", "atmrt_generate_device", "atmrt_last_hits_device", "atmrt_last_timings", "atmrt_coloring_from_conf", "atmrt_draw_image",
             "atmrt_draw_image_device", "atmrt_ray_paths", "atmrt_atmosphere_sample",
             "atmrt_coords_at_dist"]

@@ -86,6 +86,7 @@ struct atmrt_ctx {
   DensePlanes last_dense{};
   PackedHits last_hits{};
   const uint64_t* last_offset = nullptr;
+  uint64_t last_nhits = 0;
 
   std::vector<ObjectDev> objects;      // host image of the device table (altitude kind in _pad until k_resolve)
   std::vector<uint8_t> textures;       // RGBA8 pool
@@ -931,6 +932,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->last_dense = dense;
   c->last_hits = packed;
   c->last_offset = ws.hit_offset;
+  c->last_nhits = c->last_packed ? counters[1] : 0;
   return ATMRT_OK;
 }
 
@@ -1088,6 +1090,38 @@ extern "C" int atmrt_generate_device(atmrt_ctx* c, const atmrt_device_planes_t* 
   dense.normal = planes->normal;
   uint64_t n_hits = 0;
   return run_generator(c, f, ws, dense, false, nullptr, &n_hits, ray_steps, device_ms);
+}
+
+extern "C" int atmrt_last_hits_device(atmrt_ctx* c, const atmrt_device_hits_t* dst, uint64_t* n_hits) {
+  if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_last_hits_device needs a frame: call atmrt_generate_device first");
+  if (!c->last_packed)
+    return c->fail(ATMRT_ERR_STATE, "the last frame holds first-hit planes only (opaque scene through atmrt_generate_device): "
+                                    "its trace points are the planes themselves");
+  const uint64_t n = c->last_nhits;
+  if (n_hits) *n_hits = n;
+  if (!dst) return ATMRT_OK; // size query
+  if (dst->capacity < n)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "capacity %llu is less than the %llu trace points of the frame",
+                   (unsigned long long)dst->capacity, (unsigned long long)n);
+  if (!dst->hit_offset || !dst->lat || !dst->lon || !dst->distance || !dst->elevation || !dst->path_length || !dst->normal ||
+      !dst->color_tag || !dst->rgba)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "every array pointer must be a device allocation");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const PackedHits& h = c->last_hits;
+  auto d2d = [&](void* to, const void* from, size_t bytes) { return bytes ? hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s) : hipSuccess; };
+  HIP_TRY(c, d2d(dst->hit_offset, c->last_offset, c->last_npx * 8));
+  HIP_TRY(c, d2d(dst->lat, h.lat, n * 8));
+  HIP_TRY(c, d2d(dst->lon, h.lon, n * 8));
+  HIP_TRY(c, d2d(dst->distance, h.distance, n * 8));
+  HIP_TRY(c, d2d(dst->elevation, h.elevation, n * 8));
+  HIP_TRY(c, d2d(dst->path_length, h.path_length, n * 8));
+  HIP_TRY(c, d2d(dst->normal, h.normal, n * 24));
+  HIP_TRY(c, d2d(dst->color_tag, h.color_tag, n * 4));
+  HIP_TRY(c, d2d(dst->rgba, h.rgba, n * 32));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  return ATMRT_OK;
 }
 
 extern "C" int atmrt_last_timings(atmrt_ctx* c, atmrt_timings_t* out) {

@@ -154,6 +154,24 @@ class Generator:
         return steps.value, ms.value
 
 
+    def last_hits_device(self, height, width):
+        """Complete trace-point lists of the frame generate_device just produced, as torch tensors on the context's device:
+        {hit_offset [H][W], lat, lon, distance, elevation, path_length, normal [n][3], color_tag, rgba [n][4]}."""
+        import torch
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.atmrt_last_hits_device(self.ctx.handle, None, C.byref(n)))
+        n = n.value
+        dev = torch.device("cuda", self.ctx.device)
+        f64 = dict(dtype=torch.float64, device=dev)
+        t = {k: torch.empty(n, **f64) for k in ("lat", "lon", "distance", "elevation", "path_length")}
+        t["normal"] = torch.empty((n, 3), **f64)
+        t["rgba"] = torch.empty((n, 4), **f64)
+        t["color_tag"] = torch.empty(n, dtype=torch.int32, device=dev)
+        t["hit_offset"] = torch.empty((height, width), dtype=torch.int64, device=dev)
+        pod = _abi.DeviceHits(capacity=n, **{k: v.data_ptr() for k, v in t.items()})
+        self.ctx.check(self.ctx.lib.atmrt_last_hits_device(self.ctx.handle, C.byref(pod), None))
+        return t
+
     def last_timings(self):
         t = _abi.Timings()
         self.ctx.check(self.ctx.lib.atmrt_last_timings(self.ctx.handle, C.byref(t)))

@@ -132,6 +132,9 @@ def main():
         gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in local.items()}
 
     gather_events, gather_ms = [], {}
+    multi_hit = args.terrain_alpha < 1.0 or args.objects > 0
+    gathered_hits = [None, None, None]
+    from atm_raytracer_amd.sharding import all_gather_hits
 
     def make_step(generator_name):
         cfg.params.generator = _abi.GENERATORS[generator_name]
@@ -150,6 +153,13 @@ def main():
                         gathered[k].copy_(host)
                     else:
                         dist.all_gather_into_tensor(gathered[k], v)
+                if multi_hit:  # pixels with several trace points: gather the variable-length lists as well
+                    hits = gen.last_hits_device(H, wl)
+                    hits.pop("hit_offset")
+                    hc = local["hit_count"]
+                    if backend == "gloo":
+                        hits, hc = {k: v.cpu() for k, v in hits.items()}, hc.cpu()
+                    gathered_hits[:] = all_gather_hits(hc, hits, world, dist)
                 ev1.record()
             return steps, gen.last_timings()
         return step
@@ -280,6 +290,10 @@ def main():
         hits = assemble(gathered["hit_count"].view((world,) + tuple(local["hit_count"].shape)))
         log(f"gathered image check: shape {tuple(full.shape)}, rank-0 shard matches: {bool(ok)}, hit pixels per rank shard: "
             f"{[int((hits[:, g * wl:(g + 1) * wl] > 0).sum()) for g in range(world)]}")
+        if multi_hit:
+            counts, offsets, lists = gathered_hits
+            log(f"gathered trace-point lists: {lists['lat'].shape[0]} points, sum of hit_count {int(counts.sum())}, "
+                f"last offset + count {int(offsets[-1, -1]) + int(counts[-1, -1])}")
     ctx.close()
     if distributed:
         dist.destroy_process_group()

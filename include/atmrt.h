@@ -230,6 +230,24 @@ void atmrt_result_free(atmrt_result_t* r);
 int atmrt_generate_device(atmrt_ctx* ctx, const atmrt_device_planes_t* planes, uint64_t* ray_steps,
                           double* device_ms);
 
+/* The complete trace-point lists of the frame atmrt_generate_device just produced (translucent terrain, scenes with objects,
+ * InterpolatingRectilinear), copied device-to-device into caller-owned arrays laid out like the hit arrays of atmrt_result_t:
+ * what a multi-GPU host gathers after the hit_count planes.  dst == NULL only queries *n_hits.  An opaque frame has
+ * no list beyond its planes: ATMRT_ERR_STATE. */
+typedef struct atmrt_device_hits {
+  uint64_t capacity;     /* entries each hit array can hold */
+  uint64_t* hit_offset;  /* [H][Wshard] index of each pixel's first trace point */
+  double* lat;
+  double* lon;
+  double* distance;
+  double* elevation;
+  double* path_length;
+  double* normal;        /* [n][3] */
+  uint32_t* color_tag;
+  double* rgba;          /* [n][4] */
+} atmrt_device_hits_t;
+int atmrt_last_hits_device(atmrt_ctx* ctx, const atmrt_device_hits_t* dst, uint64_t* n_hits);
+
 /* Device time of each phase of the last atmrt_generate / atmrt_generate_device call, measured with HIP
  * events recorded on the library's own streams (a caller's events on another stream cannot see them). */
 typedef struct atmrt_timings {

@@ -73,6 +73,54 @@ def test_two_rank_column_shards_reassemble(generator, oracle_det):
         assert np.array_equal(got[k], want[k], equal_nan=True), k
 
 
+HIT_FIELDS = ("lat", "lon", "distance", "elevation", "path_length", "normal", "color_tag", "rgba")
+
+
+def hits_worker(rank, world, port, width, height, queue):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from atm_raytracer_amd import sharding, synth
+    from oracle_binding import Oracle
+    from util import run_oracle
+    cfg, tiles = synth.scene("S2", width, height, generator="Fast", max_distance=60_000.0, level=301, terrain_alpha=0.4, tilt=-4.0)
+    c0, c1 = sharding.column_shard(width, rank, world)
+    cfg.params.col_begin, cfg.params.col_end = c0, c1
+    res = run_oracle(Oracle("det"), cfg, tiles, n_threads=2)
+    hc = torch.from_numpy(np.ascontiguousarray(res["hit_count"].astype(np.int32)))
+    hits = {k: torch.from_numpy(np.ascontiguousarray(res[k].astype(np.int32) if k == "color_tag" else res[k])) for k in HIT_FIELDS}
+    counts, offsets, full = sharding.all_gather_hits(hc, hits, world, dist)
+    if rank == 0:
+        queue.put((counts.numpy(), offsets.numpy(), {k: v.numpy() for k, v in full.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_variable_length_hit_lists(oracle_det):
+    """terrain_alpha < 1 (BASELINE config 5's shape of result): pixels hold several trace points, shards hold different numbers
+    of them.  hit_count planes -> global offsets -> padded all-gather -> scatter must rebuild the unsharded frame's lists."""
+    from atm_raytracer_amd import synth
+    from util import run_oracle
+    width, height, world = 40, 16, 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=hits_worker, args=(r, world, port, width, height, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    counts, offsets, full = queue.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg, tiles = synth.scene("S2", width, height, generator="Fast", max_distance=60_000.0, level=301, terrain_alpha=0.4, tilt=-4.0)
+    want = run_oracle(oracle_det, cfg, tiles)
+    assert want["hit_count"].max() > 1 and np.array_equal(counts, want["hit_count"])
+    assert np.array_equal(offsets, want["hit_offset"].astype(np.int64))
+    for k in HIT_FIELDS:
+        assert np.array_equal(full[k], want[k].astype(full[k].dtype)), k
+
+
 def test_assemble_layout():
     from atm_raytracer_amd import sharding
     g, h, wl = 4, 3, 5

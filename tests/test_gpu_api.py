@@ -213,3 +213,32 @@ def test_two_contexts_compute_the_two_halves(oracle_det):
         assert np.array_equal(np.concatenate([r[k] for r in parts], axis=1), want[k]), k
     assert parts[0]["ray_steps"] + parts[1]["ray_steps"] == want["ray_steps"]
     assert parts[0]["n_hits"] + parts[1]["n_hits"] == want["n_hits"]
+
+
+def test_last_hits_device_matches_host_result(gpu_ctx):
+    """atmrt_last_hits_device: the trace-point lists left in HBM by atmrt_generate_device (what a multi-GPU host gathers for
+    translucent / object scenes) are those atmrt_generate returns; opaque frames have none and say so."""
+    import torch
+    cfg, tiles = synth.scene("S2", 64, 32, generator="Rectilinear", terrain_alpha=0.5, tilt=-4.0)
+    want = run_gpu(gpu_ctx, cfg, tiles)
+    g = generators.make_generator(generators.Params(cfg), generators.Terrain(gpu_ctx))
+    dev = torch.device("cuda", 0)
+    h, w = 32, 64
+    t = {k: torch.zeros((h, w), dtype=torch.float64, device=dev) for k in ("azimuth", "elevation_angle", "lat", "lon", "distance", "elevation", "path_length")}
+    t["normal"] = torch.zeros((3, h, w), dtype=torch.float64, device=dev)
+    t["hit_count"] = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    g.generate_device(_abi.DevicePlanes(**{k: v.data_ptr() for k, v in t.items()}))
+    hits = g.last_hits_device(h, w)
+    assert hits["lat"].shape[0] == want["n_hits"] > 0
+    assert np.array_equal(hits["hit_offset"].cpu().numpy(), want["hit_offset"].astype(np.int64))
+    for k in ("lat", "lon", "distance", "elevation", "path_length", "normal", "rgba"):
+        assert np.array_equal(hits[k].cpu().numpy(), want[k]), k
+    assert np.array_equal(hits["color_tag"].cpu().numpy().astype(np.uint32), want["color_tag"])
+    # too small a capacity is refused; an opaque frame has no list
+    n = C.c_uint64()
+    pod = _abi.DeviceHits(capacity=want["n_hits"] - 1, **{k: v.data_ptr() for k, v in hits.items()})
+    assert gpu_ctx.lib.atmrt_last_hits_device(gpu_ctx.handle, C.byref(pod), C.byref(n)) == _abi.ERR_INVALID_ARGUMENT and n.value == want["n_hits"]
+    cfg.params.terrain_alpha = 1.0
+    g2 = generators.make_generator(generators.Params(cfg), generators.Terrain(gpu_ctx))
+    g2.generate_device(_abi.DevicePlanes(**{k: v.data_ptr() for k, v in t.items()}))
+    assert gpu_ctx.lib.atmrt_last_hits_device(gpu_ctx.handle, None, C.byref(n)) == _abi.ERR_STATE

@@ -215,8 +215,12 @@ static __device__ __forceinline__ int close_ids(const Frame& f, const Earth& e, 
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
 // utils.rs:72-88), then the step logic above.
+// 2 waves per SIMD (256 VGPRs): config 5 measured 958 ms; 3 waves (more spills) 993 ms
+#ifndef ATMRT_TRACE_WAVES
+#define ATMRT_TRACE_WAVES 2
+#endif
 template <bool FILL, int CALC, bool CUBIC>
-__global__ __launch_bounds__(256) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
+__global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
                                                     PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
                                                     uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,

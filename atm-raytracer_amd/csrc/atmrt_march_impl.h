@@ -24,7 +24,8 @@ namespace atmrt {
 // finite-difference terrain lookups per sample and the interpolation.  Keeping the hit epilogue out
 // of the march keeps the RK4 loop at ~135 VGPRs without scratch.
 
-// 4 waves per SIMD (<= 128 VGPRs): measured 790 ms (3 waves) -> 702 ms (4) on the headline frame; 5 and 6 spill
+// 4 waves per SIMD (<= 128 VGPRs, 116 B/lane of spilled loop state): headline frame 402 ms (3 waves, no spills) / 366 ms (4) /
+// 419 ms (5) with the current n(h) code; the first version of the kernel: 790 ms (3) / 702 ms (4)
 #ifndef ATMRT_MARCH_WAVES
 #define ATMRT_MARCH_WAVES 4
 #endif

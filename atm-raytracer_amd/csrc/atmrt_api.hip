@@ -919,9 +919,9 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   }
   (void)fast;
   if (counters[2])
-    return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step, "
-                   "more than %d objects close to one sample, or more than %d trace points in four lattice corners",
-                   (unsigned long long)counters[2], 12, 8, 64);
+    return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step "
+                   "or more than %d trace points in four lattice corners",
+                   (unsigned long long)counters[2], 12, 64);
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;

@@ -207,8 +207,8 @@ static __device__ __forceinline__ int close_ids(const Frame& f, const Earth& e, 
   for (int q = 0; q < total; q++) {
     const int j = use_cand ? cand[q] : q;
     if (object_is_close(e, f.objects[j], t)) {
-      if (n < CLOSE_CAP) ids[n++] = j;
-      else atomicOr(&counters[2], 2ull);
+      if (n < CLOSE_CAP) ids[n] = j;
+      n++; // the true count: a sample with more than CLOSE_CAP close objects sends its two steps through the unlisted path
     }
   }
   return n;
@@ -283,17 +283,26 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         }
         if (n0 | n1) {
           Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
-          int ia = 0, ib = 0;
-          while (ia < n0 || ib < n1) {
-            int idx;
-            if (ib >= n1 || (ia < n0 && ids0[ia] <= ids1[ib])) {
-              idx = ids0[ia];
-              if (ib < n1 && ids1[ib] == idx) ib++;
-              ia++;
-            } else {
-              idx = ids1[ib++];
+          if (n0 <= CLOSE_CAP && n1 <= CLOSE_CAP) {
+            int ia = 0, ib = 0;
+            while (ia < n0 || ib < n1) { // union of the two ascending lists
+              int idx;
+              if (ib >= n1 || (ia < n0 && ids0[ia] <= ids1[ib])) {
+                idx = ids0[ia];
+                if (ib < n1 && ids1[ib] == idx) ib++;
+                ia++;
+              } else {
+                idx = ids1[ib++];
+              }
+              step_object(hits, f, idx, pos1, pos2, counters);
             }
-            step_object(hits, f, idx, pos1, pos2, counters);
+          } else { // more close objects than a list holds: the same union, taken directly over the candidates in ascending order
+            const LatLonTrig t0 = latlon_trig(e, lat0, lon0), t1 = latlon_trig(e, lat1, lon1);
+            const int total = use_cand ? ncand : f.n_objects;
+            for (int q = 0; q < total; q++) {
+              const int j = use_cand ? cand[q] : q;
+              if (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)) step_object(hits, f, j, pos1, pos2, counters);
+            }
           }
         }
         if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;

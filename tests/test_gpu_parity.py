@@ -231,6 +231,16 @@ def test_objects_in_a_line_overflow_the_candidate_list(gpu_ctx, oracle_det):
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
 
 
+def test_more_close_objects_than_the_per_lane_list(gpu_ctx, oracle_det):
+    """14 cylinders inside one 150 m stretch: the samples next to them see more close objects (TerrainData.objects_close,
+    utils.rs:74-80) than the 8 the Rectilinear tracer lists per lane; those steps take the unlisted path — same trace points."""
+    cfg, tiles = synth.scene("S2", 48, 24, generator="Rectilinear", terrain_alpha=0.5, max_distance=20_000.0, tilt=-2.0)
+    synth.add_objects(cfg, n_cyl=14, n_bill=0, dist=(1_500.0, 1_650.0), spread_deg=1.5, radius=(30.0, 60.0), height=(300.0, 700.0))
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert (got["color_tag"] == 1).sum() > 20
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
 EARTHS = ["SimpleSphere", {"Spherical": {"radius": 6371000.0}}, {"Spherical": {"radius": 3.0e6}}, "Wgs84",
           {"Ellipsoid": {"a": 6378137.0, "b": 6300000.0}}, "AzimuthalEquidistant", "FlatDistorted",
           {"ObserverAe": {"proj_radius": 6371000.0}}, "SimpleObserverAe"]
@@ -241,7 +251,7 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     """Seeded random sweep over the parameter space (earth model, direction incl. the 0/360 wrap, tilt, field of view, observer
     altitude kind, non-integer steps whose accumulated distances round, straight / refracted, opaque / translucent, generator,
     wavelength, and — for a third of the seeds — a random atmosphere: 1-4 Linear layers with lapse, isothermal and inversion
-    gradients, or a Spline temperature profile): every f64 field and every hit decision must match the oracle bit for bit.
+    gradients, or a Spline temperature profile — and for a quarter random scene objects): every f64 field and every hit decision must match the oracle bit for bit.
     ATMRT_RANDOM_SEEDS widens the sweep (400 seeds were run once when the division/exp/log sequences changed)."""
     rng = np.random.default_rng(1000 + seed)
     gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
@@ -279,6 +289,12 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
                                  "next_functions": [{"altitude": float(a), "function": {"Linear": {"gradient": g}}} for a, g in zip(alts, grads[1:])]}
     from atm_raytracer_amd import config
     cfg = config.Config.from_dict(doc)
+    if seed % 4 == 3 or seed >= 36:  # scene objects in a quarter of the sweep (every generator, opaque and translucent terrain)
+        ro = np.random.default_rng(9000 + seed)
+        if seed % 4 == 3 or ro.uniform() < 0.4:
+            synth.add_objects(cfg, n_cyl=int(ro.integers(3, 40)), n_bill=int(ro.integers(0, 12)), dist=(200.0, float(ro.uniform(2_000.0, 20_000.0))),
+                              spread_deg=float(ro.uniform(5.0, 60.0)), radius=(20.0, 150.0), height=(100.0, 700.0), bill_w=(100.0, 500.0),
+                              bill_h=(100.0, 500.0), seed=int(ro.integers(1 << 30)))
     tiles = synth.synth_tiles([46], [8], level=301)
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))

@@ -117,7 +117,7 @@ static __device__ __forceinline__ Earth earth_for(const Frame& f) {
 // Two passes (count -> exclusive scan -> fill) because the trace-point lists have variable length.
 // ---------------------------------------------------------------------------------------------
 constexpr int STEP_CANDIDATES = 12; // trace points one step may produce here (terrain + 4 per object); more sets the error flag
-constexpr int CLOSE_CAP = 8;        // Rectilinear: objects close to one sample listed per lane; a sample with more is handled unlisted
+
 
 struct StepHits {
   int n;

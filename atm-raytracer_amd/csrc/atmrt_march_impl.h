@@ -198,20 +198,16 @@ static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Eart
   return true;
 }
 
-// proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the candidates or over every object
-static __device__ __forceinline__ int close_ids(const Frame& f, const Earth& e, double lat, double lon, bool use_cand,
-                                                const int* cand, int ncand, int* ids, unsigned long long* counters) {
+// proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the ray's candidates: bit q = cand[q] is close.
+// Any number of close objects fits (the candidate list has at most CAND_CAP = 24 entries), and the union over the two samples
+// of a step is an OR; set bits ascending = object indices ascending.
+static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Earth& e, double lat, double lon, const int* cand,
+                                                      int ncand) {
   const LatLonTrig t = latlon_trig(e, lat, lon);
-  int n = 0;
-  const int total = use_cand ? ncand : f.n_objects;
-  for (int q = 0; q < total; q++) {
-    const int j = use_cand ? cand[q] : q;
-    if (object_is_close(e, f.objects[j], t)) {
-      if (n < CLOSE_CAP) ids[n] = j;
-      n++; // the true count: a sample with more than CLOSE_CAP close objects sends its two steps through the unlisted path
-    }
-  }
-  return n;
+  unsigned m = 0;
+  for (int q = 0; q < ncand; q++)
+    if (object_is_close(e, f.objects[cand[q]], t)) m |= 1u << q;
+  return m;
 }
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
@@ -256,10 +252,12 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
       double lat0, lon0;
       coords_at_dist(e, c, 0.0, lat0, lon0);
       double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
-      int ids0[CLOSE_CAP], ids1[CLOSE_CAP], cand[CAND_CAP];
+      int cand[CAND_CAP];
       int ncand = 0;
+      // rays with a candidate list keep the close objects of a sample as a bit mask over it; the others (more than CAND_CAP
+      // candidates, or a DirectionalCalc without the pre-filter) test every object against both samples of a step
       const bool use_cand = ray_candidates<CALC>(f, e, c, cand, ncand);
-      int n0 = close_ids(f, e, lat0, lon0, use_cand, cand, ncand, ids0, counters), n1 = 0;
+      unsigned m0 = use_cand ? close_mask(f, e, lat0, lon0, cand, ncand) : 0u, m1 = 0u;
       double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh_ = alt, path_length = 0.0;
       for (int i = 1;; i++) {
@@ -271,7 +269,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         double lat1, lon1;
         coords_at_dist(e, c, sx, lat1, lon1);
         double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
-        n1 = close_ids(f, e, lat1, lon1, use_cand, cand, ncand, ids1, counters);
+        m1 = use_cand ? close_mask(f, e, lat1, lon1, cand, ncand) : 0u;
         steps++;
         StepHits hits;
         hits.n = 0;
@@ -281,29 +279,21 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
           step_push(hits, diff1 / (diff1 - diff2), -1, nullptr, counters);
           if (terrain_opaque) hits.finish = true;
         }
-        if (n0 | n1) {
-          Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
-          if (n0 <= CLOSE_CAP && n1 <= CLOSE_CAP) {
-            int ia = 0, ib = 0;
-            while (ia < n0 || ib < n1) { // union of the two ascending lists
-              int idx;
-              if (ib >= n1 || (ia < n0 && ids0[ia] <= ids1[ib])) {
-                idx = ids0[ia];
-                if (ib < n1 && ids1[ib] == idx) ib++;
-                ia++;
-              } else {
-                idx = ids1[ib++];
-              }
-              step_object(hits, f, idx, pos1, pos2, counters);
-            }
-          } else { // more close objects than a list holds: the same union, taken directly over the candidates in ascending order
-            const LatLonTrig t0 = latlon_trig(e, lat0, lon0), t1 = latlon_trig(e, lat1, lon1);
-            const int total = use_cand ? ncand : f.n_objects;
-            for (int q = 0; q < total; q++) {
-              const int j = use_cand ? cand[q] : q;
-              if (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)) step_object(hits, f, j, pos1, pos2, counters);
+        if (use_cand) {
+          unsigned m = m0 | m1;
+          if (m) {
+            Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
+            while (m) {
+              const int q = __builtin_ctz(m);
+              m &= m - 1;
+              step_object(hits, f, cand[q], pos1, pos2, counters);
             }
           }
+        } else if (f.n_objects) {
+          const LatLonTrig t0 = latlon_trig(e, lat0, lon0), t1 = latlon_trig(e, lat1, lon1);
+          Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
+          for (int j = 0; j < f.n_objects; j++)
+            if (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)) step_object(hits, f, j, pos1, pos2, counters);
         }
         if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;
         if (hits.n && (FILL || count + (unsigned)hits.n <= (unsigned)RECT_SLOTS)) {
@@ -320,8 +310,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         count += (unsigned)hits.n;
         if (hits.finish) break;
         lat0 = lat1; lon0 = lon1; te0 = te1; re0 = sh_; d0 = sx; pl0 = path_length;
-        n0 = n1;
-        for (int q = 0; q < CLOSE_CAP; q++) ids0[q] = ids1[q];
+        m0 = m1;
       }
     }
     if (!FILL) {

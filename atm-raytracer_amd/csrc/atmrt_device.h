@@ -148,6 +148,9 @@ static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int 
 }
 
 // collisions of one object with the segment, utils.rs:251-278
+static __device__ __forceinline__ bool object_out_of_band(const ObjectDev& o, double re0, double re1) {
+  return (re0 < o.vlo && re1 < o.vlo) || (re0 > o.vhi && re1 > o.vhi); // false for NaN: the geometry then decides
+}
 static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2,
                                                    unsigned long long* counters) {
   Collision col[4];

@@ -81,6 +81,8 @@ struct Workspace {
   double* pelev;          // [h][n_path_cap] Fast: ray elevation per row
   double* plen;           // [h][n_path_cap] Fast: running path length per row
   int32_t* npath;         // [h]
+  double* pelev_t;        // [n_path_cap][h] scenes with objects: pelev / plen sample-major for k_fast_trace (lanes = rows)
+  double* plen_t;
   int32_t* hit_step;      // [h][wl] first hit: index of the older sample of the pair, or -1
   uint64_t* hit_offset;   // [h][wl] exclusive scan of hit_count
   uint64_t* scan_tmp;     // block sums for the scan

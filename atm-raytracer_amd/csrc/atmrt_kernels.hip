@@ -323,51 +323,128 @@ __global__ __launch_bounds__(256) void k_close_objects(Frame f, const double* __
   if (!FILL) ccount[s] = c;
 }
 
-// Fast, phase C, general.  One pixel per lane (x fastest: every load of the sample-major caches is coalesced).
+// Fast, phase C, general (scene objects: the full get_single_pixel, utils.rs:201-289).
+// One image COLUMN per wavefront, lanes = 64 adjacent rows.  Everything that depends on the column only — the terrain
+// profile value of a sample, its close-object list — is wave-uniform: scalar loads, and the "does this sample pair have close
+// objects" test is a scalar branch, so the object logic runs for whole wavefronts at the 2 % of cells that need it and the
+// other steps are a handful of vector instructions per row (one coalesced load of the ray elevations, which k_paths_transpose
+// lays out sample-major for this kernel).  Inside an object cell a lane joins the geometry only if its segment enters the
+// height band of an object (object_out_of_band).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __restrict__ prof,
                                                     const double* __restrict__ plat, const double* __restrict__ plon,
                                                     const uint32_t* __restrict__ ccount,
                                                     const uint64_t* __restrict__ coffset,
-                                                    const uint32_t* __restrict__ clist, const double* __restrict__ pelev,
-                                                    const double* __restrict__ plen, const int32_t* __restrict__ npath,
+                                                    const uint32_t* __restrict__ clist, const double* __restrict__ pelev_t,
+                                                    const double* __restrict__ plen_t, const int32_t* __restrict__ npath,
                                                     uint32_t* __restrict__ hit_count,
                                                     const uint64_t* __restrict__ hit_offset, PackedHits packed,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     uint32_t* __restrict__ px_steps,
                                                     unsigned long long* __restrict__ counters) {
-  int x = blockIdx.x * blockDim.x + threadIdx.x;
-  int y = blockIdx.y;
-  unsigned long long steps = 0;
-  if (x < f.wl) {
-    int n = npath[y];
-    n = n < f.n_t ? n : f.n_t;
-    const size_t p = (size_t)y * f.wl + x;
-    const double* row = pelev + (size_t)y * f.n_path_cap;
-    const double* lrow = plen + (size_t)y * f.n_path_cap;
-    const bool terrain_opaque = f.p.terrain_alpha == 1.0;
-    uint64_t k = FILL ? hit_offset[p] : 0;
-    unsigned count = 0;
-    double te0 = prof[x], re0 = row[0];
-    uint32_t c0 = ccount[x];
-    for (int i = 1; i < n; i++) {
-      size_t s1 = (size_t)i * f.wl + x, s0 = s1 - f.wl;
-      double te1 = prof[s1], re1 = row[i];
-      uint32_t c1 = ccount[s1];
-      StepHits sh;
-      sh.n = 0;
-      sh.finish = false;
-      steps++;
-      double diff1 = re0 - te0, diff2 = re1 - te1;
-      if (diff1 * diff2 < 0.0) { // utils.rs:222-240
-        step_push(sh, diff1 / (diff1 - diff2), -1, nullptr, counters);
-        if (terrain_opaque) sh.finish = true;
+  // caches written by earlier kernels, read-only here: through the constant address space a wave-uniform index is a scalar load
+  typedef const __attribute__((address_space(4))) double* ConstF64;
+  typedef const __attribute__((address_space(4))) uint32_t* ConstU32;
+  typedef const __attribute__((address_space(4))) uint64_t* ConstU64;
+  typedef const __attribute__((address_space(4))) ObjectDev* ConstObj;
+  const ConstF64 kprof = (ConstF64)(uintptr_t)prof, kplat = (ConstF64)(uintptr_t)plat, kplon = (ConstF64)(uintptr_t)plon;
+  const ConstU32 kccount = (ConstU32)(uintptr_t)ccount, kclist = (ConstU32)(uintptr_t)clist;
+  const ConstU64 kcoffset = (ConstU64)(uintptr_t)coffset;
+  const ConstObj kobjects = (ConstObj)(uintptr_t)f.objects;
+  const int lane = threadIdx.x & 63;
+  const int x = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); // wave-uniform column
+  const int y = blockIdx.y * 64 + lane;
+  if (x >= f.wl) return; // whole wavefront
+  const bool row_ok = y < f.h;
+  const size_t hh = (size_t)f.h;
+  const bool terrain_opaque = f.p.terrain_alpha == 1.0;
+  int n = 0;
+  if (row_ok) {
+    n = npath[y];
+    n = n < f.n_t ? n : f.n_t; // Iterator::zip, fast.rs:59-62
+  }
+  int nmax = n;
+  for (int o = 32; o; o >>= 1) {
+    const int v = __shfl_xor(nmax, o, 64);
+    nmax = v > nmax ? v : nmax;
+  }
+  const size_t p = (size_t)(row_ok ? y : 0) * f.wl + x;
+  uint64_t k = (FILL && row_ok) ? hit_offset[p] : 0;
+  unsigned count = 0, stp = 0;
+  bool active = n > 1;
+  double te0 = kprof[x], re0 = n > 0 ? pelev_t[y] : 0.0;
+  uint32_t c0 = kccount[x];
+  constexpr int TCH = 8; // samples fetched ahead: every step's scalar loads would otherwise be a dependent round trip
+  int i = 1;
+  while (i < nmax) {
+    if (!__any(active)) break;
+    if (c0 == 0 && i + TCH <= nmax) {
+      double te[TCH], re[TCH];
+      uint32_t cc = 0;
+#pragma unroll
+      for (int q = 0; q < TCH; q++) {
+        te[q] = kprof[(size_t)(i + q) * f.wl + x];
+        cc |= kccount[(size_t)(i + q) * f.wl + x];
+        re[q] = i + q < n ? pelev_t[(size_t)(i + q) * hh + y] : 0.0;
       }
-      if (c0 | c1) { // utils.rs:241-280, union in ascending index order
-        double lat0 = plat[s0], lon0 = plon[s0], lat1 = plat[s1], lon1 = plon[s1];
-        Vec3 pos1 = as_cartesian(f.earth, lat0, lon0, re0), pos2 = as_cartesian(f.earth, lat1, lon1, re1);
-        const uint32_t* la = clist + coffset[s0];
-        const uint32_t* lb = clist + coffset[s1];
+      if (cc == 0) { // no close objects anywhere in the chunk: terrain only, utils.rs:222-240
+#pragma unroll
+        for (int q = 0; q < TCH; q++) {
+          active = active && i + q < n;
+          stp += active ? 1u : 0u;
+          const double diff1 = re0 - te0, diff2 = re[q] - te[q];
+          if (active && diff1 * diff2 < 0.0) {
+            if (FILL) {
+              list_step[k] = (uint32_t)(i + q - 1);
+              list_pixel[k] = (uint32_t)p;
+              packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
+              k++;
+            }
+            count++;
+            if (terrain_opaque) active = false;
+          }
+          te0 = te[q];
+          re0 = re[q];
+        }
+        i += TCH;
+        continue;
+      }
+    }
+    { // one sample pair, with or without close objects
+    const size_t s1 = (size_t)i * f.wl + x, s0 = s1 - f.wl;
+    const double te1 = kprof[s1];
+    const uint32_t c1 = kccount[s1];
+    const bool in_path = i < n;
+    const double re1 = in_path ? pelev_t[(size_t)i * hh + y] : 0.0;
+    active = active && in_path;
+    stp += active ? 1u : 0u;
+    const double diff1 = re0 - te0, diff2 = re1 - te1;
+    const bool hit = active && diff1 * diff2 < 0.0; // utils.rs:222
+    if ((c0 | c1) == 0) { // wave-uniform: no close objects at either sample — terrain only (utils.rs:222-240)
+      if (hit) {
+        if (FILL) {
+          list_step[k] = (uint32_t)(i - 1);
+          list_pixel[k] = (uint32_t)p;
+          packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
+          k++;
+        }
+        count++;
+        if (terrain_opaque) active = false;
+      }
+    } else { // the same for every lane: the union of the two ascending close lists (utils.rs:241-280)
+      const ConstU32 la = kclist + kcoffset[s0];
+      const ConstU32 lb = kclist + kcoffset[s1];
+      if (active) {
+        StepHits sh;
+        sh.n = 0;
+        sh.finish = false;
+        if (hit) {
+          step_push(sh, diff1 / (diff1 - diff2), -1, nullptr, counters);
+          if (terrain_opaque) sh.finish = true;
+        }
+        const double lat0 = kplat[s0], lon0 = kplon[s0], lat1 = kplat[s1], lon1 = kplon[s1];
+        bool have_pos = false;
+        Vec3 pos1 = v3(0.0, 0.0, 0.0), pos2 = pos1;
         uint32_t ia = 0, ib = 0;
         while (ia < c0 || ib < c1) {
           uint32_t idx;
@@ -378,29 +455,50 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
           } else {
             idx = lb[ib++];
           }
+          const double vlo = kobjects[idx].vlo, vhi = kobjects[idx].vhi;
+          if ((re0 < vlo && re1 < vlo) || (re0 > vhi && re1 > vhi)) continue; // most rows pass above or below the object
+          if (!have_pos) {
+            pos1 = as_cartesian(f.earth, lat0, lon0, re0);
+            pos2 = as_cartesian(f.earth, lat1, lon1, re1);
+            have_pos = true;
+          }
           step_object(sh, f, (int)idx, pos1, pos2, counters);
         }
         if (FILL && sh.n)
           step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, i == 1 ? 0.0 : f.xs[i - 1],
-                    i == 1 ? 0.0 : lrow[i - 1], lat1, lon1, re1, f.xs[i], lrow[i]);
-      } else if (FILL && sh.n) { // terrain only: the finalize kernel recomputes the geodesic points
-        step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, 0.0, 0.0, re0, 0.0, 0.0, 0.0, 0.0, re1, 0.0, 0.0);
+                    i == 1 ? 0.0 : plen_t[(size_t)(i - 1) * hh + y], lat1, lon1, re1, f.xs[i], plen_t[(size_t)i * hh + y]);
+        count += (unsigned)sh.n;
+        if (sh.finish) active = false;
       }
-      count += (unsigned)sh.n;
-      if (sh.finish) break;
-      te0 = te1;
-      re0 = re1;
-      c0 = c1;
     }
-    if (!FILL) {
-      hit_count[p] = count;
-      if (px_steps) px_steps[p] = (uint32_t)steps;
+    te0 = te1;
+    re0 = re1;
+    c0 = c1;
+
     }
+    i++;
+  }
+  if (!FILL && row_ok) {
+    hit_count[p] = count;
+    if (px_steps) px_steps[p] = stp;
   }
   if (!FILL) {
-    steps = wave_sum(steps);
-    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+    unsigned long long steps = wave_sum((unsigned long long)(row_ok ? stp : 0u));
+    if (lane == 0 && steps) atomicAdd(&counters[0], steps);
   }
+}
+
+// pelev / plen [h][n_path_cap] -> [n_path_cap][h] for k_fast_trace (lanes = rows)
+__global__ __launch_bounds__(256) void k_paths_transpose(Frame f, const double* __restrict__ pelev, const double* __restrict__ plen,
+                                                         const int32_t* __restrict__ npath, double* __restrict__ pelev_t,
+                                                         double* __restrict__ plen_t) {
+  const int y = blockIdx.y * blockDim.x + threadIdx.x; // rows on grid.y (h < 32768), samples on grid.x (up to 4e6)
+  const int i = blockIdx.x;
+  if (y >= f.h) return;
+  const bool have = i < npath[y]; // entries past the end of a row's path were never written
+  const size_t src = (size_t)y * f.n_path_cap + i, dst = (size_t)i * f.h + y;
+  pelev_t[dst] = have ? pelev[src] : 0.0;
+  plen_t[dst] = have ? plen[src] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1008,8 +1106,10 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
     return;
   }
   PackedHits none = {};
-  hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
-                     ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, out.hit_count, (const uint64_t*)nullptr, none,
+  hipLaunchKernelGGL(k_paths_transpose, dim3(f.n_path_cap, cdiv(f.h, 256)), dim3(256), 0, stream, f, ws.pelev, ws.plen, ws.npath,
+                     ws.pelev_t, ws.plen_t);
+  hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
+                     ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, out.hit_count, (const uint64_t*)nullptr, none,
                      (uint32_t*)nullptr, (uint32_t*)nullptr, ws.px_steps, (unsigned long long*)ws.counters);
 }
 
@@ -1019,8 +1119,8 @@ void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
     launch_rect_trace_fill(f, ws, n_hits, dense, packed, stream);
     return;
   }
-  hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
-                     ws.ccount, ws.coffset, ws.clist, ws.pelev, ws.plen, ws.npath, dense.hit_count, ws.hit_offset, packed,
+  hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
+                     ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, dense.hit_count, ws.hit_offset, packed,
                      ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,

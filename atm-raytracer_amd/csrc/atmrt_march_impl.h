@@ -281,6 +281,8 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         }
         if (use_cand) {
           unsigned m = m0 | m1;
+          for (unsigned mm = m; mm; mm &= mm - 1) // drop the objects whose height band the segment does not enter
+            if (object_out_of_band(f.objects[cand[__builtin_ctz(mm)]], re0, sh_)) m &= ~(mm & (0u - mm));
           if (m) {
             Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
             while (m) {
@@ -293,7 +295,8 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
           const LatLonTrig t0 = latlon_trig(e, lat0, lon0), t1 = latlon_trig(e, lat1, lon1);
           Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
           for (int j = 0; j < f.n_objects; j++)
-            if (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)) step_object(hits, f, j, pos1, pos2, counters);
+            if (!object_out_of_band(f.objects[j], re0, sh_) && (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)))
+              step_object(hits, f, j, pos1, pos2, counters);
         }
         if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;
         if (hits.n && (FILL || count + (unsigned)hits.n <= (unsigned)RECT_SLOTS)) {

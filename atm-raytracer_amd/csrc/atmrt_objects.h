@@ -20,6 +20,7 @@ struct ObjectDev {
   Vec3 pos;               // earth_model.as_cartesian(&self.position)
   Vec3 up;                // earth_model.world_directions(lat, lon).2
   double close2;          // 2 (r + sim_step)^2 of Object::is_close
+  double vlo, vhi;        // a ray segment whose elevations lie entirely below vlo or above vhi cannot touch the object
 };
 
 // sin/cos of a sample's latitude and longitude, shared by every as_cartesian of that sample
@@ -56,6 +57,15 @@ ATMRT_HD void object_derive(const Earth& e, double sim_step, ObjectDev& o) {
   world_directions(e, o.lat, o.lon, n, ea, o.up);
   double r = o.kind == ATMRT_OBJ_FRUSTUM ? (o.r1 > o.r2 ? o.r1 : o.r2) : o.width; // frustum.rs:111, billboard.rs:77
   o.close2 = 2.0 * (r + sim_step) * (r + sim_step);
+  // Every collision of frustum.rs / billboard.rs has its coordinate along `up` in [0, height].  For a point of a segment
+  // between two samples that coordinate is its elevation minus o.elev, less the curvature drop over its horizontal offset
+  // (<= reach^2 / 2R; only close objects are tested, so the offset is below reach) and give or take the chord's sagitta
+  // (step^2 / 8R).  Both are doubled here and 2 m added: segments outside [vlo, vhi] are skipped before any geometry.
+  double rr = e.cart == 1 ? e.cart_radius : e.cart == 2 ? (e.a < e.b ? e.a : e.b) : 0.0;
+  double reach = dm_sqrt(o.close2) + sim_step;
+  double curv = e.cart == 0 ? 0.0 : (sim_step * sim_step / 4.0 + reach * reach) / rr;
+  o.vlo = o.elev - 2.0 - curv;
+  o.vhi = o.elev + (o.height > 0.0 ? o.height : 0.0) + 2.0 + curv;
 }
 
 // Object::is_close, frustum.rs:103-114 / billboard.rs:68-78

@@ -96,7 +96,7 @@ struct atmrt_ctx {
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
-      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t;
+      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -268,7 +268,7 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
                     &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
-                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t})
+                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand})
     b->release();
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -634,6 +634,12 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
     HIP_TRY(c, c->d_pelev_t.reserve((size_t)f.h * f.n_path_cap * sizeof(double)));
     HIP_TRY(c, c->d_plen_t.reserve((size_t)f.h * f.n_path_cap * sizeof(double)));
   }
+  if (f.p.generator != ATMRT_GEN_RECTILINEAR && f.n_objects > 0) {
+    HIP_TRY(c, c->d_col_cand.reserve((size_t)f.wl * 64 * sizeof(int32_t)));
+    HIP_TRY(c, c->d_col_ncand.reserve((size_t)f.wl * sizeof(int32_t)));
+  }
+  ws->col_cand = c->d_col_cand.as<int32_t>();
+  ws->col_ncand = c->d_col_ncand.as<int32_t>();
   ws->pelev_t = c->d_pelev_t.as<double>();
   ws->plen_t = c->d_plen_t.as<double>();
   ws->npath = c->d_npath.as<int32_t>();

@@ -81,6 +81,31 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
   return v;
 }
 
+// Objects that can EVER be close to a sample of this ray (exact superset of Object::is_close over the whole ray).
+// Spherical model: every sample, lifted to the object's elevation, lies in the great-circle plane span(pos, dir) of the
+// ray's ground track, so |P - P_obj| >= distance of P_obj to that plane.  Azimuthal-equidistant model: the ground track
+// is a straight line of the flat map and z differences vanish, same argument with the line.  A millimetre of slack
+// covers the rounding of the recomputed sample positions.  Other models (ellipsoid geodesics, lat/lon-linear tracks):
+// no pre-filter.  Returns false when the list overflowed (the caller then tests every object, still exact).
+constexpr int CAND_CAP = 24;
+template <int CALC, int CAP>
+static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n) {
+  n = 0;
+  if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
+  Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
+  for (int j = 0; j < f.n_objects; j++) {
+    const ObjectDev& o = f.objects[j];
+    Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
+    double dperp = dm_fabs(dot(rel, nrm));
+    double reach = dm_sqrt(o.close2) + 1.0e-3;
+    if (dperp <= reach) {
+      if (n >= CAP) return false;
+      cand[n++] = j;
+    }
+  }
+  return true;
+}
+
 // A translation unit that defines DM_TABLES_LDS (see detmath.h) calls this first in every kernel: exp/log tables -> LDS.
 __device__ __forceinline__ void stage_dm_tables() {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DM_TABLES_LDS)

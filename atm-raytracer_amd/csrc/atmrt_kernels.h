@@ -104,6 +104,8 @@ struct Workspace {
   uint32_t* ccount;       // [n_t][wl] number of close objects
   uint64_t* coffset;      // [n_t][wl] exclusive scan of ccount
   uint32_t* clist;        // object indices, ascending per sample
+  int32_t* col_cand;      // [wl][64] objects that can be close to any sample of the column (ascending), and ...
+  int32_t* col_ncand;     // ... their number; -1 = no list, test every object
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
 };
 

@@ -304,17 +304,45 @@ __global__ __launch_bounds__(256) void k_dense_from_packed(Frame f, const uint64
 }
 
 // Fast, phase A extras: which objects are close to each terrain sample (TerrainData::from_lat_lon, utils.rs:74-80)
+// Objects that can be close to ANY sample of a column (ray_candidates: exact superset, from the column's ground track), so that
+// the per-sample proximity filter below tests a handful of objects instead of all of them.  ncand[x] < 0: no list for the
+// column (more than COL_CAND candidates, or a DirectionalCalc without the pre-filter) — every object is tested.
+constexpr int COL_CAND = 64;
+template <int CALC>
+__global__ __launch_bounds__(64) void k_column_candidates(Frame f, const DirCalc* __restrict__ colcalc, int32_t* __restrict__ ccand,
+                                                          int32_t* __restrict__ ncand) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= f.wl) return;
+  int cand[COL_CAND];
+  int n = 0;
+  const bool ok = ray_candidates<CALC, COL_CAND>(f, f.earth, colcalc[x], cand, n);
+  ncand[x] = ok ? n : -1;
+  if (ok)
+    for (int q = 0; q < n; q++) ccand[(size_t)x * COL_CAND + q] = cand[q];
+}
+
+// TerrainData::from_lat_lon's proximity filter (utils.rs:74-80) for every (sample, column): count, then fill ascending lists
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_close_objects(Frame f, const double* __restrict__ plat,
-                                                       const double* __restrict__ plon, uint32_t* __restrict__ ccount,
+                                                       const double* __restrict__ plon, const int32_t* __restrict__ ccand,
+                                                       const int32_t* __restrict__ ncand, uint32_t* __restrict__ ccount,
                                                        const uint64_t* __restrict__ coffset, uint32_t* __restrict__ clist) {
   size_t n = (size_t)f.n_t * f.wl;
   size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
+  const int x = (int)(s % (size_t)f.wl);
+  const int nc = ncand[x];
+  const int32_t* cand = ccand + (size_t)x * COL_CAND;
+  if (nc == 0) { // nothing can be close to this column
+    if (!FILL) ccount[s] = 0;
+    return;
+  }
   const LatLonTrig t = latlon_trig(f.earth, plat[s], plon[s]);
   uint32_t c = 0;
   uint64_t k = FILL ? coffset[s] : 0;
-  for (int j = 0; j < f.n_objects; j++) {
+  const int total = nc < 0 ? f.n_objects : nc;
+  for (int q = 0; q < total; q++) {
+    const int j = nc < 0 ? q : cand[q];
     if (object_is_close(f.earth, f.objects[j], t)) {
       if (FILL) clist[k + c] = (uint32_t)j;
       c++;
@@ -1071,16 +1099,18 @@ void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count
 
 void launch_close_count(const Frame& f, Workspace& ws, hipStream_t stream) {
   size_t n = (size_t)f.n_t * f.wl;
-  hipLaunchKernelGGL((k_close_objects<false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.ccount,
-                     (const uint64_t*)nullptr, (uint32_t*)nullptr);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_column_candidates<CALC>), dim3(cdiv(f.wl, 64)), dim3(64), 0, stream, f,
+                                                        ws.colcalc, ws.col_cand, ws.col_ncand));
+  hipLaunchKernelGGL((k_close_objects<false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.col_cand,
+                     ws.col_ncand, ws.ccount, (const uint64_t*)nullptr, (uint32_t*)nullptr);
   // total number of list entries -> counters[3]
   launch_scan_u32(ws.ccount, n, ws.scan_tmp, ws.coffset, (unsigned long long*)ws.counters + 2, stream);
 }
 
 void launch_close_fill(const Frame& f, Workspace& ws, hipStream_t stream) {
   size_t n = (size_t)f.n_t * f.wl;
-  hipLaunchKernelGGL((k_close_objects<true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.ccount,
-                     ws.coffset, ws.clist);
+  hipLaunchKernelGGL((k_close_objects<true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.col_cand,
+                     ws.col_ncand, ws.ccount, ws.coffset, ws.clist);
 }
 
 void launch_pack_first_hits(const Frame& f, Workspace& ws, const DensePlanes& dense, const PackedHits& packed,

@@ -173,31 +173,6 @@ __global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_
 }
 
 
-// Objects that can EVER be close to a sample of this ray (exact superset of Object::is_close over the whole ray).
-// Spherical model: every sample, lifted to the object's elevation, lies in the great-circle plane span(pos, dir) of the
-// ray's ground track, so |P - P_obj| >= distance of P_obj to that plane.  Azimuthal-equidistant model: the ground track
-// is a straight line of the flat map and z differences vanish, same argument with the line.  A millimetre of slack
-// covers the rounding of the recomputed sample positions.  Other models (ellipsoid geodesics, lat/lon-linear tracks):
-// no pre-filter.  Returns false when the list overflowed (the caller then tests every object, still exact).
-constexpr int CAND_CAP = 24;
-template <int CALC>
-static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n) {
-  n = 0;
-  if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
-  Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
-  for (int j = 0; j < f.n_objects; j++) {
-    const ObjectDev& o = f.objects[j];
-    Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
-    double dperp = dm_fabs(dot(rel, nrm));
-    double reach = dm_sqrt(o.close2) + 1.0e-3;
-    if (dperp <= reach) {
-      if (n >= CAND_CAP) return false;
-      cand[n++] = j;
-    }
-  }
-  return true;
-}
-
 // proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the ray's candidates: bit q = cand[q] is close.
 // Any number of close objects fits (the candidate list has at most CAND_CAP = 24 entries), and the union over the two samples
 // of a step is an OR; set bits ascending = object indices ascending.
@@ -256,7 +231,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
       int ncand = 0;
       // rays with a candidate list keep the close objects of a sample as a bit mask over it; the others (more than CAND_CAP
       // candidates, or a DirectionalCalc without the pre-filter) test every object against both samples of a step
-      const bool use_cand = ray_candidates<CALC>(f, e, c, cand, ncand);
+      const bool use_cand = ray_candidates<CALC, CAND_CAP>(f, e, c, cand, ncand);
       unsigned m0 = use_cand ? close_mask(f, e, lat0, lon0, cand, ncand) : 0u, m1 = 0u;
       double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh_ = alt, path_length = 0.0;

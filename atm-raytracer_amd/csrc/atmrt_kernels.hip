@@ -370,6 +370,10 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     uint32_t* __restrict__ px_steps,
                                                     unsigned long long* __restrict__ counters) {
+  // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
+  // (packed / list_step / list_pixel then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its
+  // place in the pixel-ordered list — for the pixels that did not fit their slots (hit_count > RECT_SLOTS); the others were
+  // moved by k_fast_gather_trace_slots and their lanes are idle here (most wavefronts leave at once).
   // caches written by earlier kernels, read-only here: through the constant address space a wave-uniform index is a scalar load
   typedef const __attribute__((address_space(4))) double* ConstF64;
   typedef const __attribute__((address_space(4))) uint32_t* ConstU32;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
   const size_t p = (size_t)(row_ok ? y : 0) * f.wl + x;
   uint64_t k = (FILL && row_ok) ? hit_offset[p] : 0;
   unsigned count = 0, stp = 0;
-  bool active = n > 1;
+  bool active = n > 1 && (!FILL || hit_count[p] > (uint32_t)RECT_SLOTS);
   double te0 = kprof[x], re0 = n > 0 ? pelev_t[y] : 0.0;
   uint32_t c0 = kccount[x];
   constexpr int TCH = 8; // samples fetched ahead: every step's scalar loads would otherwise be a dependent round trip
@@ -422,10 +426,11 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
           stp += active ? 1u : 0u;
           const double diff1 = re0 - te0, diff2 = re[q] - te[q];
           if (active && diff1 * diff2 < 0.0) {
-            if (FILL) {
-              list_step[k] = (uint32_t)(i + q - 1);
-              list_pixel[k] = (uint32_t)p;
-              packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
+            if (FILL || count < (unsigned)RECT_SLOTS) {
+              const uint64_t kw = FILL ? k : (uint64_t)p * RECT_SLOTS + count;
+              list_step[kw] = (uint32_t)(i + q - 1);
+              list_pixel[kw] = (uint32_t)p;
+              packed.color_tag[kw] = ATMRT_COLOR_TERRAIN;
               k++;
             }
             count++;
@@ -450,10 +455,11 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
     const bool hit = active && diff1 * diff2 < 0.0; // utils.rs:222
     if ((c0 | c1) == 0) { // wave-uniform: no close objects at either sample — terrain only (utils.rs:222-240)
       if (hit) {
-        if (FILL) {
-          list_step[k] = (uint32_t)(i - 1);
-          list_pixel[k] = (uint32_t)p;
-          packed.color_tag[k] = ATMRT_COLOR_TERRAIN;
+        if (FILL || count < (unsigned)RECT_SLOTS) {
+          const uint64_t kw = FILL ? k : (uint64_t)p * RECT_SLOTS + count;
+          list_step[kw] = (uint32_t)(i - 1);
+          list_pixel[kw] = (uint32_t)p;
+          packed.color_tag[kw] = ATMRT_COLOR_TERRAIN;
           k++;
         }
         count++;
@@ -492,7 +498,8 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
           }
           step_object(sh, f, (int)idx, pos1, pos2, counters);
         }
-        if (FILL && sh.n)
+        if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;
+        if (sh.n && (FILL || count + (unsigned)sh.n <= (unsigned)RECT_SLOTS))
           step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, i == 1 ? 0.0 : f.xs[i - 1],
                     i == 1 ? 0.0 : plen_t[(size_t)(i - 1) * hh + y], lat1, lon1, re1, f.xs[i], plen_t[(size_t)i * hh + y]);
         count += (unsigned)sh.n;
@@ -513,6 +520,38 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
   if (!FILL) {
     unsigned long long steps = wave_sum((unsigned long long)(row_ok ? stp : 0u));
     if (lane == 0 && steps) atomicAdd(&counters[0], steps);
+  }
+}
+
+// Trace points kept in the slot arena by the counting pass of k_fast_trace, moved to their places in the pixel-ordered list
+// (object points are complete; terrain points are completed by k_fast_finalize_list from list_step / list_pixel).
+__global__ __launch_bounds__(256) void k_fast_gather_trace_slots(Frame f, const uint32_t* __restrict__ hit_count,
+                                                                 const uint64_t* __restrict__ hit_offset,
+                                                                 const uint32_t* __restrict__ slot_step, PackedHits sp,
+                                                                 uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                                 PackedHits packed) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const uint32_t n = hit_count[p];
+  if (n > (uint32_t)RECT_SLOTS) return; // written by the fill pass
+  const uint64_t k0 = hit_offset[p];
+  for (uint32_t j = 0; j < n; j++) {
+    const size_t q = p * RECT_SLOTS + j;
+    const uint64_t k = k0 + j;
+    list_step[k] = slot_step[q];
+    list_pixel[k] = (uint32_t)p;
+    const uint32_t tag = sp.color_tag[q];
+    packed.color_tag[k] = tag;
+    if (tag != ATMRT_COLOR_TERRAIN) {
+      packed.lat[k] = sp.lat[q];
+      packed.lon[k] = sp.lon[q];
+      packed.distance[k] = sp.distance[q];
+      packed.elevation[k] = sp.elevation[q];
+      packed.path_length[k] = sp.path_length[q];
+      for (int c = 0; c < 3; c++) packed.normal[3 * k + c] = sp.normal[3 * q + c];
+      for (int c = 0; c < 4; c++) packed.rgba[4 * k + c] = sp.rgba[4 * q + c];
+    }
   }
 }
 
@@ -1135,12 +1174,11 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
     launch_rect_trace_count(f, ws, out, stream);
     return;
   }
-  PackedHits none = {};
   hipLaunchKernelGGL(k_paths_transpose, dim3(f.n_path_cap, cdiv(f.h, 256)), dim3(256), 0, stream, f, ws.pelev, ws.plen, ws.npath,
                      ws.pelev_t, ws.plen_t);
   hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
-                     ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, out.hit_count, (const uint64_t*)nullptr, none,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr, ws.px_steps, (unsigned long long*)ws.counters);
+                     ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, out.hit_count, (const uint64_t*)nullptr,
+                     ws.slot_packed, ws.slot_step, ws.slot_pixel, ws.px_steps, (unsigned long long*)ws.counters);
 }
 
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
@@ -1149,6 +1187,8 @@ void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
     launch_rect_trace_fill(f, ws, n_hits, dense, packed, stream);
     return;
   }
+  hipLaunchKernelGGL(k_fast_gather_trace_slots, dim3(cdiv((size_t)f.wl * f.h, 256)), dim3(256), 0, stream, f,
+                     (const uint32_t*)dense.hit_count, ws.hit_offset, ws.slot_step, ws.slot_packed, ws.list_step, ws.list_pixel, packed);
   hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                      ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, dense.hit_count, ws.hit_offset, packed,
                      ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters);

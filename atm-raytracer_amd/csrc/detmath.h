@@ -227,17 +227,17 @@ DM_FN double dm_atan(double x) {
   } else if (ax < 1.1875) {
     if (ax < 0.6875) {
       id = 0; hi = 0.4636476090008061; lo = 2.2698777452961687e-17;
-      t = (2.0 * ax - 1.0) / (2.0 + ax);
+      t = dm_div(2.0 * ax - 1.0, 2.0 + ax);
     } else {
       id = 1; hi = 0.7853981633974483; lo = 3.061616997868383e-17;
-      t = (ax - 1.0) / (ax + 1.0);
+      t = dm_div(ax - 1.0, ax + 1.0);
     }
   } else if (ax < 2.4375) {
     id = 2; hi = 0.982793723247329; lo = 1.3903311031230998e-17;
-    t = (ax - 1.5) / (1.0 + 1.5 * ax);
+    t = dm_div(ax - 1.5, 1.0 + 1.5 * ax);
   } else {
     id = 3; hi = 1.5707963267948966; lo = 6.123233995736766e-17;
-    t = -1.0 / ax;
+    t = dm_div(-1.0, ax); /* 2.4375 <= ax < 2^66 */
   }
   z = t * t;
   w = z * z;
@@ -302,20 +302,20 @@ DM_FN double dm_asin(double x) {
     t = x * x;
     p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
     q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-    return x + x * (p / q);
+    return x + x * dm_div(p, q);
   }
   w = 1.0 - ax;
   t = w * 0.5;
   p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
   q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
-  s = dm_sqrt(t);
+  s = dm_sqrt_inrange(t); /* 2^-54 <= t <= 0.25 */
   if (ax >= 0.975) {
-    w = p / q;
+    w = dm_div(p, q);
     res = pio2_hi - (2.0 * (s + s * w) - pio2_lo);
   } else {
     w = dm_from_bits(dm_bits(s) & 0xffffffff00000000ULL);
-    c = (t - w * w) / (s + w);
-    r = p / q;
+    c = dm_div(t - w * w, s + w);
+    r = dm_div(p, q);
     p = 2.0 * s * r - (pio2_lo - 2.0 * c);
     q = pio4_hi - 2.0 * w;
     res = pio4_hi - (p - q);
@@ -423,7 +423,11 @@ DM_FN double dm_log_slow(double x) { /* nan, negative, zero, inf, subnormal */
   if (dm_isinf(x)) return x;
   return dm_log_core(x * 18014398509481984.0, -54); /* subnormal: scale by 2^54 */
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN int dm_log_in_main_range(double x) { return __builtin_amdgcn_class(x, 0x100); } /* positive normal: one v_cmp_class */
+#else
 DM_FN int dm_log_in_main_range(double x) { return x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308; }
+#endif
 DM_FN double dm_log(double x) {
   if (!dm_log_in_main_range(x)) return dm_log_slow(x);
   return dm_log_core(x, 0);

@@ -405,8 +405,8 @@ ATMRT_HD double refr_dn_hint(const AtmTable& a, double h, int& hint) {
 // three evaluations and their instruction streams interleave (the table look-ups of exp/log are the long latencies here).
 template <bool CUBIC>
 ATMRT_HD void refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, double& dn) {
-  const double eps = 0.01;
 #if defined(__HIP_DEVICE_COMPILE__)
+  const double eps = 0.01;
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   const double h1 = h - eps, h2 = h + eps;
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads

@@ -241,6 +241,19 @@ def test_more_close_objects_than_the_per_lane_list(gpu_ctx, oracle_det):
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
 
 
+@pytest.mark.parametrize("kw", [dict(generator="Rectilinear", tilt=55.0, fov=60.0, max_distance=400_000.0, step=500.0),
+                                dict(generator="Fast", tilt=55.0, fov=60.0, max_distance=400_000.0, step=500.0),
+                                dict(generator="Rectilinear", tilt=-60.0, fov=50.0, max_distance=50_000.0),
+                                dict(generator="Rectilinear", tilt=-2.0, max_distance=900_000.0, step=20_000.0)],
+                         ids=["above-the-atmosphere-rect", "above-the-atmosphere-fast", "steep-down", "20-km-steps"])
+def test_out_of_envelope_rays(gpu_ctx, oracle_det, kw):
+    """Rays that leave the envelope the in-range division / sqrt / exp-log shortcuts are argued for: 300 km up, where the
+    linear continuation of US-76 reaches T <= 0 and n(h) is NaN; a view straight down; 20 km steps (chord sagitta of metres).
+    The GPU must still agree with the oracle bit for bit, NaN propagation and step counts included."""
+    cfg, tiles = synth.scene("S2", 40, 24, **kw)
+    assert_bitexact(run_gpu(gpu_ctx, cfg, tiles), run_oracle(oracle_det, cfg, tiles))
+
+
 EARTHS = ["SimpleSphere", {"Spherical": {"radius": 6371000.0}}, {"Spherical": {"radius": 3.0e6}}, "Wgs84",
           {"Ellipsoid": {"a": 6378137.0, "b": 6300000.0}}, "AzimuthalEquidistant", "FlatDistorted",
           {"ObserverAe": {"proj_radius": 6371000.0}}, "SimpleObserverAe"]

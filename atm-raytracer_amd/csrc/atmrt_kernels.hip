@@ -666,37 +666,51 @@ __global__ __launch_bounds__(256) void k_fov_table(Frame f, double* __restrict__
   elev[(size_t)y * f.p.width + x] = e;
 }
 // min_elev_step per column :470-491 and min_dir_step per row :493-517 (before the global min and * SCALE)
+// Both are minima over a whole column / row; they are folded in parallel (the values are positive, so their bit patterns order
+// like the numbers and an integer atomicMin merges the partial results exactly).
+constexpr int FOV_ROW_CHUNKS = 32;
+__global__ __launch_bounds__(256) void k_fov_colmin_init(Frame f, double* __restrict__ colmin) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < f.p.width) colmin[x] = dm_to_radians(360.0);
+}
 __global__ __launch_bounds__(256) void k_fov_colmin(Frame f, const double* __restrict__ elev, double* __restrict__ colmin) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= f.p.width) return;
   const int W = f.p.width, H = f.p.height;
+  const int per = (H - 1 + FOV_ROW_CHUNKS - 1) / FOV_ROW_CHUNKS;
+  const int y0 = 1 + blockIdx.y * per, y1 = y0 + per < H ? y0 + per : H; // this block's diffs: rows y0 .. y1 - 1 against y - 1
+  if (y0 >= y1) return;
   const double min_diff = dm_to_radians(f.p.frame.fov) / (double)f.p.width / 3.0;
-  double mn = dm_to_radians(360.0), last = elev[x];
-  for (int y = 1; y < H; y++) {
+  double mn = dm_to_radians(360.0), last = elev[(size_t)(y0 - 1) * W + x];
+  for (int y = y0; y < y1; y++) {
     double next = elev[(size_t)y * W + x];
     double diff = dm_fabs(next - last);
     if (diff < min_diff) diff = min_diff;
     if (diff < mn) mn = diff;
     last = next;
   }
-  colmin[x] = mn;
+  atomicMin((unsigned long long*)&colmin[x], (unsigned long long)dm_bits(mn));
 }
-__global__ __launch_bounds__(64) void k_fov_rowmin(Frame f, const double* __restrict__ dir, double* __restrict__ rowmin) {
-  int y = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_fov_rowmin(Frame f, const double* __restrict__ dir, double* __restrict__ rowmin) {
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6); // one row per wavefront
+  const int lane = threadIdx.x & 63;
   if (y >= f.p.height) return;
   const int W = f.p.width;
   const double full = dm_to_radians(360.0);
   const double min_diff = dm_to_radians(f.p.frame.fov) / (double)f.p.width / 3.0;
-  double mn = full, last = dir[(size_t)y * W];
-  for (int x = 1; x < W; x++) {
-    double next = dir[(size_t)y * W + x];
-    double diff = dm_fabs(next - last);
+  const double* row = dir + (size_t)y * W;
+  double mn = full;
+  for (int x = 1 + lane; x < W; x += 64) {
+    double diff = dm_fabs(row[x] - row[x - 1]);
     if (diff > full) diff -= full;
     if (diff < min_diff) diff = min_diff;
     if (diff < mn) mn = diff;
-    last = next;
   }
-  rowmin[y] = mn;
+  for (int o = 32; o; o >>= 1) {
+    const double v = __shfl_xor(mn, o, 64);
+    mn = v < mn ? v : mn;
+  }
+  if (lane == 0) rowmin[y] = mn;
 }
 
 static __device__ __forceinline__ int sat_i32(double v) { // Rust `f as i32`
@@ -950,8 +964,9 @@ __global__ __launch_bounds__(256) void k_lattice_steps(size_t n, const uint8_t* 
 
 void launch_fov_table(const Frame& f, const InterpBuffers& ib, hipStream_t stream) {
   hipLaunchKernelGGL(k_fov_table, dim3(cdiv(f.p.width, 256), f.p.height), dim3(256), 0, stream, f, ib.dir, ib.elev);
-  hipLaunchKernelGGL(k_fov_colmin, dim3(cdiv(f.p.width, 256)), dim3(256), 0, stream, f, ib.elev, ib.colmin);
-  hipLaunchKernelGGL(k_fov_rowmin, dim3(cdiv(f.p.height, 64)), dim3(64), 0, stream, f, ib.dir, ib.rowmin);
+  hipLaunchKernelGGL(k_fov_colmin_init, dim3(cdiv(f.p.width, 256)), dim3(256), 0, stream, f, ib.colmin);
+  hipLaunchKernelGGL(k_fov_colmin, dim3(cdiv(f.p.width, 256), FOV_ROW_CHUNKS), dim3(256), 0, stream, f, ib.elev, ib.colmin);
+  hipLaunchKernelGGL(k_fov_rowmin, dim3(cdiv(f.p.height, 4)), dim3(256), 0, stream, f, ib.dir, ib.rowmin);
 }
 void launch_lattice_keys(const Frame& f, const InterpBuffers& ib, double min_elev_step, double min_dir_step, hipStream_t stream) {
   const size_t npx = (size_t)f.wl * f.h;

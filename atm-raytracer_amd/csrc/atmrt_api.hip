@@ -17,6 +17,7 @@
 
 #include "atmrt_kernels.h"
 #include "atmrt_render.h"
+#include "atmrt_tiff.h"
 
 using namespace atmrt;
 
@@ -319,6 +320,20 @@ extern "C" int atmrt_terrain_load_dir(atmrt_ctx* c, const char* path, int32_t* n
     int lat0, lon0;
     std::string msg;
     int rc = read_dted(full.c_str(), &lat0, &lon0, &t, &msg);
+    if (rc == ATMRT_ERR_FORMAT && atmrt_tiff::coords_from_name(ent->d_name, lat0, lon0)) {
+      // not DTED, but named like a GeoTIFF tile (terrain/mod.rs:100-118 -> geotiff.rs).  The reference opens such a file lazily and
+      // treats a failure as "no elevation here"; so does this loader: an undecodable file leaves its cell empty (0 m).
+      std::string why;
+      t = HostTile{};
+      if (atmrt_tiff::read_dem(full, 3601, t.posts, why)) {
+        t.n_lat = t.n_lon = 3601; // geotiff.rs:70-71: a 3600-interval grid per degree, file row = latitude index
+        c->tiles[{lat0, lon0}] = std::move(t);
+      } else {
+        c->tiles.erase({lat0, lon0});
+      }
+      files++;
+      continue;
+    }
     if (rc) {
       closedir(d);
       return c->fail(rc, "%s", msg.c_str());

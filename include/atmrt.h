@@ -201,7 +201,9 @@ void atmrt_ctx_destroy(atmrt_ctx* ctx);
 const char* atmrt_last_error(const atmrt_ctx* ctx);
 
 /* ---- terrain: replaces Terrain::{from_folder,get_elev} (terrain/mod.rs:55-126) + crate dted 0.2 */
-/* Scan a directory of DTED files (every entry must parse, as terrain/mod.rs:113-118 panics otherwise). */
+/* Scan a terrain directory (Terrain::from_folder, terrain/mod.rs:66-118): every entry must be a DTED file or be named like a
+ * GeoTIFF tile ((N|S)dd(E|W)ddd, 16-bit single band, at least 3601 x 3601 samples); anything else fails as the reference
+ * panics.  A GeoTIFF that cannot be decoded leaves its cell without terrain, like the reference's lazy load. */
 int atmrt_terrain_load_dir(atmrt_ctx* ctx, const char* path, int32_t* n_files);
 /* Register one 1-degree cell directly.  posts: n_lat rows (south to north) of n_lon posts (west to east). */
 int atmrt_terrain_add_tile(atmrt_ctx* ctx, int32_t lat0, int32_t lon0, int32_t n_lat, int32_t n_lon,

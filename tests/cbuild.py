@@ -23,3 +23,13 @@ def dm_export():
 
 def core_host():
     return _build("core_host.cpp", "libcore_host.so", ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"])
+
+
+def tiff_export():
+    out = os.path.join(OUT, "libtiff_export.so")
+    src = os.path.join(HERE, "csrc", "tiff_export.cpp")
+    hdr = os.path.join(HERE, "..", "atm-raytracer_amd", "csrc", "atmrt_tiff.h")
+    os.makedirs(OUT, exist_ok=True)
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in (src, hdr)):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", out, src, "-lz"], check=True)
+    return out

@@ -88,8 +88,14 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
 // covers the rounding of the recomputed sample positions.  Other models (ellipsoid geodesics, lat/lon-linear tracks):
 // no pre-filter.  Returns false when the list overflowed (the caller then tests every object, still exact).
 constexpr int CAND_CAP = 24;
+// With lo/hi the distance interval of every candidate is returned as well: the stepper distances x at which a sample can be
+// close to it.  Spherical: the angle between the sample's and the object's directions is at least their along-track angle
+// difference |x/R - phi_j| and must stay below 2 asin(reach / 2(R + elev)); flat map: the along-track coordinate differs by
+// less than reach.  The bounds are widened by 0.1 % + 1 mm (and to the whole ray for reaches above 1 % of the radius or
+// objects below the surface by more than the radius), so they are a superset like the list itself.
 template <int CALC, int CAP>
-static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n) {
+static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n,
+                                                      double* lo = nullptr, double* hi = nullptr) {
   n = 0;
   if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
   Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
@@ -100,6 +106,19 @@ static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Eart
     double reach = dm_sqrt(o.close2) + 1.0e-3;
     if (dperp <= reach) {
       if (n >= CAP) return false;
+      if (lo) {
+        double along, half = reach * 1.001 + 1.0e-3;
+        if (CALC == 2) {
+          along = e.calc_radius * dm_atan2(dot(o.pos, c.dir), dot(o.pos, c.pos));
+          if (o.elev < 0.0) half = half * (e.cart_radius / (e.cart_radius + o.elev));
+          if (!(reach < 0.01 * e.cart_radius) || !(half > 0.0) || !(e.calc_radius == e.cart_radius)) half = dm_inf();
+        } else {
+          along = dot(rel, c.dir);
+        }
+        lo[n] = along - half;
+        hi[n] = along + half;
+        if (!(lo[n] <= hi[n])) lo[n] = -dm_inf(), hi[n] = dm_inf(); // NaN anywhere: no restriction
+      }
       cand[n++] = j;
     }
   }

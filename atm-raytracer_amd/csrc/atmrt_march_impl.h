@@ -228,11 +228,16 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
       coords_at_dist(e, c, 0.0, lat0, lon0);
       double te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
       int cand[CAND_CAP];
+      double clo[CAND_CAP], chi[CAND_CAP];
       int ncand = 0;
       // rays with a candidate list keep the close objects of a sample as a bit mask over it; the others (more than CAND_CAP
-      // candidates, or a DirectionalCalc without the pre-filter) test every object against both samples of a step
-      const bool use_cand = ray_candidates<CALC, CAND_CAP>(f, e, c, cand, ncand);
+      // candidates, or a DirectionalCalc without the pre-filter) test every object against both samples of a step.
+      // x_wake: the first stepper distance at which any candidate can be close — before it the proximity filter is skipped.
+      const bool use_cand = ray_candidates<CALC, CAND_CAP>(f, e, c, cand, ncand, clo, chi);
       unsigned m0 = use_cand ? close_mask(f, e, lat0, lon0, cand, ncand) : 0u, m1 = 0u;
+      double x_wake = dm_inf();
+      for (int q = 0; q < ncand; q++)
+        if (chi[q] >= 0.0) x_wake = clo[q] < x_wake ? clo[q] : x_wake;
       double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh_ = alt, path_length = 0.0;
       for (int i = 1;; i++) {
@@ -244,7 +249,13 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         double lat1, lon1;
         coords_at_dist(e, c, sx, lat1, lon1);
         double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
-        m1 = use_cand ? close_mask(f, e, lat1, lon1, cand, ncand) : 0u;
+        m1 = 0u;
+        if (use_cand && sx >= x_wake) { // inside (or past the start of) some candidate's interval
+          m1 = close_mask(f, e, lat1, lon1, cand, ncand);
+          x_wake = dm_inf(); // next distance of interest: the earliest start among the intervals not yet left behind
+          for (int q = 0; q < ncand; q++)
+            if (chi[q] >= sx) x_wake = clo[q] < x_wake ? clo[q] : x_wake;
+        }
         steps++;
         StepHits hits;
         hits.n = 0;

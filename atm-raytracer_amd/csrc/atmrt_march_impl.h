@@ -187,7 +187,7 @@ static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Eart
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
 // utils.rs:72-88), then the step logic above.
-// 2 waves per SIMD (256 VGPRs): config 5 measured 958 ms; 3 waves (more spills) 993 ms
+// 2 waves per SIMD (256 VGPRs): config 5 measured 642 ms; 3 waves (more spills) 700 ms, 4 waves 723 ms
 #ifndef ATMRT_TRACE_WAVES
 #define ATMRT_TRACE_WAVES 2
 #endif

@@ -61,6 +61,7 @@ struct atmrt_ctx {
   hipStream_t stream = nullptr, stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev[10] = {};
+  hipEvent_t ev_seg[FAST_SEGMENTS] = {}; // a path segment is integrated (stream2) -> its intersect scan may start
   atmrt_timings_t timings{};
   std::string error;
 
@@ -97,7 +98,7 @@ struct atmrt_ctx {
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
-      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand;
+      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -247,6 +248,13 @@ extern "C" int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal) {
     atmrt_ctx_destroy(c);
     return create_fail(ATMRT_ERR_HIP, msg);
   }
+  for (hipEvent_t& ev : c->ev_seg) {
+    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+      std::string msg = std::string("hipEventCreate: ") + hipGetErrorString(e);
+      atmrt_ctx_destroy(c);
+      return create_fail(ATMRT_ERR_HIP, msg);
+    }
+  }
   for (hipEvent_t& ev : c->ev) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) {
       std::string msg = std::string("hipEventCreate: ") + hipGetErrorString(e);
@@ -269,9 +277,11 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
                     &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
-                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand})
+                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand, &c->d_path_seg, &c->d_dprev})
     b->release();
   for (hipEvent_t ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ev_seg)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -622,6 +632,8 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
     HIP_TRY(c, c->d_pelev.reserve((size_t)f.h * f.n_path_cap * sizeof(double)));
     HIP_TRY(c, c->d_plen.reserve((size_t)f.h * f.n_path_cap * sizeof(double)));
     HIP_TRY(c, c->d_npath.reserve((size_t)f.h * sizeof(int32_t)));
+    HIP_TRY(c, c->d_path_seg.reserve((size_t)f.h * sizeof(PathSegState)));
+    if (f.n_objects == 0) HIP_TRY(c, c->d_dprev.reserve(npx * sizeof(double)));
   }
   if (f.p.generator == ATMRT_GEN_RECTILINEAR) HIP_TRY(c, c->d_rect_rec.reserve(4 * npx * sizeof(double)));
   ws->rect_rec = c->d_rect_rec.as<double>();
@@ -658,6 +670,8 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->pelev_t = c->d_pelev_t.as<double>();
   ws->plen_t = c->d_plen_t.as<double>();
   ws->npath = c->d_npath.as<int32_t>();
+  ws->path_seg = c->d_path_seg.as<PathSegState>();
+  ws->dprev = c->d_dprev.as<double>();
   ws->hit_step = c->d_hit_step.as<int32_t>();
   ws->hit_offset = c->d_hit_offset.as<uint64_t>();
   ws->scan_tmp = c->d_scan_tmp.as<uint64_t>();
@@ -738,9 +752,7 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (fast) {
-    launch_fast_caches(f, ws, s, c->stream2, c->ev_fork, c->ev_join, ev);
-    HIP_TRY(c, hipEventRecord(ev[4], s));
-    launch_fast_intersect(f, ws, dense, s);
+    launch_fast_pipeline(f, ws, dense, s, c->stream2, c->ev_fork, c->ev_seg, ev); // records ev[0..4]
     HIP_TRY(c, hipEventRecord(ev[5], s));
     if (f.opaque) launch_fast_finalize(f, ws, dense, s);
     HIP_TRY(c, hipEventRecord(ev[6], s));

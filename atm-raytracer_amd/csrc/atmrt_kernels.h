@@ -70,6 +70,12 @@ struct PackedHits {
   double* rgba;   // [n][4]
 };
 
+// State of one row's path integration at a segment boundary (k_fast_paths runs in segments, see launch_fast_pipeline)
+struct PathSegState {
+  double x, a, b, px, ph, path_length;
+  int32_t hint, n, done, n_final;
+};
+
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
 constexpr int RECT_SLOTS = 4;
@@ -81,6 +87,8 @@ struct Workspace {
   double* pelev;          // [h][n_path_cap] Fast: ray elevation per row
   double* plen;           // [h][n_path_cap] Fast: running path length per row
   int32_t* npath;         // [h]
+  PathSegState* path_seg; // [h] Fast: integration state between path segments
+  double* dprev;          // [h][wl] Fast: ray-minus-terrain difference at the last sample of the previous intersect segment
   double* pelev_t;        // [n_path_cap][h] scenes with objects: pelev / plen sample-major for k_fast_trace (lanes = rows)
   double* plen_t;
   int32_t* hit_step;      // [h][wl] first hit: index of the older sample of the pair, or -1
@@ -148,7 +156,10 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* tmp, uint64_t* out,
 void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                        hipStream_t stream);
-void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream); // atmrt_paths.hip
+void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream, int i_begin, int i_end); // atmrt_paths.hip
+constexpr int FAST_SEGMENTS = 4;
+void launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
+                          hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* timing);
 void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,
                         hipEvent_t ev_join, hipEvent_t* timing /* [0..1] phase A, [2..3] phase B */);
 void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);

@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
                                                         int32_t* __restrict__ hit_step,
                                                         uint32_t* __restrict__ hit_count,
                                                         uint32_t* __restrict__ px_steps,
-                                                        unsigned long long* __restrict__ counters) {
+                                                        unsigned long long* __restrict__ counters, double* __restrict__ dprev_state,
+                                                        int i_begin, int i_end, int last_segment) {
+  // Samples i_begin .. i_end - 1 (the frame is scanned in the segments in which its ray paths are integrated, so that the scan
+  // of one segment overlaps the integration of the next); between segments a pixel's state is the difference at its last
+  // sample (dprev_state), its first hit (hit_step) and its count (hit_count).
   constexpr int CH = 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,9 +130,21 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
     dprev[r] = prow[r][0] - t0;
   }
   int nfound = 0; // rows of this lane that have their first hit (MODE 0)
-  bool alldone = false;
-  int i = 1;
-  for (; i + CH <= nmin; i += CH) {
+  if (i_begin > 1) { // resume from the previous segment
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      const size_t p = (size_t)(y0 + r < f.h ? y0 + r : f.h - 1) * wl + xc;
+      dprev[r] = dprev_state[p];
+      first[r] = hit_step[p];
+      if (MODE == 0) nfound += first[r] >= 0 ? 1 : 0;
+      else cnt[r] = hit_count[p];
+    }
+  }
+  nmin = nmin < i_end ? nmin : i_end;
+  nmax = nmax < i_end ? nmax : i_end;
+  bool alldone = MODE == 0 && __all(nfound == RR);
+  int i = i_begin;
+  for (; !alldone && i + CH <= nmin; i += CH) {
     double t[CH];
 #pragma unroll
     for (int k = 0; k < CH; k++) t[k] = prof[(size_t)(i + k) * wl + xc];
@@ -171,6 +187,19 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
     }
   }
 
+  if (!last_segment) {
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      int y = y0 + r;
+      if (y < f.h && xok) {
+        size_t p = (size_t)y * f.wl + x;
+        dprev_state[p] = dprev[r];
+        hit_step[p] = first[r];
+        if (MODE != 0) hit_count[p] = cnt[r];
+      }
+    }
+    return;
+  }
   unsigned long long steps = 0;
 #pragma unroll
   for (int r = 0; r < RR; r++) {
@@ -1106,7 +1135,7 @@ void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipSt
   (void)hipEventRecord(ev, stream);
   (void)hipStreamWaitEvent(stream2, ev, 0);
   (void)hipEventRecord(timing[2], stream2);
-  launch_fast_paths(f, ws, stream2);
+  launch_fast_paths(f, ws, stream2, 1, f.n_path_cap);
   (void)hipEventRecord(timing[3], stream2);
   (void)hipEventRecord(ev_join, stream2);
   (void)hipEventRecord(timing[0], stream);
@@ -1124,14 +1153,52 @@ void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipSt
   (void)hipStreamWaitEvent(stream, ev_join, 0);
 }
 
-void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+static void launch_fast_intersect_segment(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, int i_begin,
+                                          int i_end, int last) {
   dim3 grid(cdiv(f.wl, 64), cdiv(f.h, 4 * FAST_RR));
   if (f.opaque)
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 0>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters);
+                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last);
   else
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 1>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters);
+                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last);
+}
+
+void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  launch_fast_intersect_segment(f, ws, out, stream, 1, f.n_path_cap, 1);
+}
+
+// Phases A, B and C of a Fast frame without scene objects.  The ray paths are one long dependent chain per row (3.5 ms at the
+// headline size on a tenth of the chip) and the intersect scan only ever needs the samples integrated so far: the paths are
+// integrated in FAST_SEGMENTS pieces on the second stream and the scan of piece k (main stream, after the terrain profile)
+// waits for piece k alone, so it overlaps the integration of piece k + 1.  timing[4] is recorded before the first scan.
+void launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
+                          hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* timing) {
+  const int cap = f.n_path_cap;
+  const int nseg = cap >= 256 ? FAST_SEGMENTS : 1;
+  int per = (cap - 1 + nseg - 1) / nseg;
+  per = (per + 3) / 4 * 4; // whole chunks of the scan
+  (void)hipEventRecord(ev_fork, stream);
+  (void)hipStreamWaitEvent(stream2, ev_fork, 0);
+  (void)hipEventRecord(timing[2], stream2);
+  for (int k = 0; k < nseg; k++) {
+    const int b0 = 1 + k * per, b1 = k == nseg - 1 ? cap : (b0 + per < cap ? b0 + per : cap);
+    launch_fast_paths(f, ws, stream2, b0, b1);
+    (void)hipEventRecord(ev_seg[k], stream2);
+  }
+  (void)hipEventRecord(timing[3], stream2);
+  (void)hipEventRecord(timing[0], stream);
+  hipLaunchKernelGGL(k_fast_columns, dim3(cdiv(f.wl, 256)), dim3(256), 0, stream, f, ws.colcalc);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC, false>),
+                                                        dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)), dim3(256), 0,
+                                                        stream, f, ws.colcalc, ws.prof, ws.plat, ws.plon));
+  (void)hipEventRecord(timing[1], stream);
+  (void)hipEventRecord(timing[4], stream);
+  for (int k = 0; k < nseg; k++) {
+    const int b0 = 1 + k * per, b1 = k == nseg - 1 ? cap : (b0 + per < cap ? b0 + per : cap);
+    (void)hipStreamWaitEvent(stream, ev_seg[k], 0);
+    launch_fast_intersect_segment(f, ws, out, stream, b0, b1, k == nseg - 1 ? 1 : 0);
+  }
 }
 
 void launch_fast_finalize(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {

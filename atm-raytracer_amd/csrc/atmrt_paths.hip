@@ -83,7 +83,11 @@ constexpr int PATH_LANES = 8; // lanes per ray
 
 template <bool CUBIC>
 __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__ pelev, double* __restrict__ plen,
-                                                   int32_t* __restrict__ npath) {
+                                                   int32_t* __restrict__ npath, PathSegState* __restrict__ seg, int i_begin,
+                                                   int i_end) {
+  // Steps i_begin .. i_end - 1 of every row.  The frame's paths are integrated in a few segments so that the intersect scan of
+  // the samples already written can run (on the other stream) while the next segment is integrated; a row's state at a
+  // segment boundary travels through `seg`.
   stage_dm_tables();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int sub = t & (PATH_LANES - 1);
@@ -99,18 +103,32 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   Stepper s;
   stepper_init(s, sph, radius, alt, dm_to_radians(frame_row_elev(f, y)));
   size_t base = (size_t)y * f.n_path_cap;
-  if (writer) {
+  if (writer && i_begin <= 1) {
     pelev[base] = alt;
     plen[base] = 0.0;
   }
   int n = 1;
   double px = 0.0, ph = alt, path_length = 0.0;
+  bool done = false;
+  int n_final = 0;
+  if (i_begin > 1) { // resume: every lane of the octet (and a surplus octet repeating the last row) reads the row's state
+    const PathSegState st0 = seg[y];
+    s.x = st0.x;
+    s.a = st0.a;
+    s.b = st0.b;
+    s.hint = st0.hint;
+    px = st0.px;
+    ph = st0.ph;
+    path_length = st0.path_length;
+    n = st0.n;
+    done = st0.done != 0;
+    n_final = st0.n_final;
+  }
   // utils.rs:159-171: push, then stop once the PREVIOUS state is beyond max_distance or below -1000 m.
   // The loop bound is wave-uniform; an octet that has finished keeps stepping without storing, so that every lane of
   // the wavefront takes part in every shuffle.
-  bool done = false;
-  int n_final = 0;
-  for (int i = 1; i < f.n_path_cap; i++) {
+  const int i_last = i_end < f.n_path_cap ? i_end : f.n_path_cap;
+  for (int i = i_begin; i < i_last; i++) {
     RayState st = rk4.next(s, sph, radius, straight, step);
     path_length += calc_dist(sph, radius, px, ph, st.x, st.h);
     if (!done) {
@@ -128,15 +146,30 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
     ph = st.h;
     if (__all(done)) break;
   }
-  if (!done) n_final = n;
-  if (writer) npath[y] = n_final;
+  if (writer) {
+    npath[y] = done ? n_final : n; // elements written so far; final after the last segment (utils.rs:160-170)
+    PathSegState st1;
+    st1.x = s.x;
+    st1.a = s.a;
+    st1.b = s.b;
+    st1.px = px;
+    st1.ph = ph;
+    st1.path_length = path_length;
+    st1.hint = s.hint;
+    st1.n = n;
+    st1.done = done ? 1 : 0;
+    st1.n_final = n_final;
+    seg[y] = st1;
+  }
 }
 
-void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream) {
+void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream, int i_begin, int i_end) {
   if (f.atm_cubic)
-    hipLaunchKernelGGL((k_fast_paths<true>), dim3(cdiv((size_t)f.h * PATH_LANES, 64)), dim3(64), 0, stream, f, ws.pelev, ws.plen, ws.npath);
+    hipLaunchKernelGGL((k_fast_paths<true>), dim3(cdiv((size_t)f.h * PATH_LANES, 64)), dim3(64), 0, stream, f, ws.pelev, ws.plen, ws.npath,
+                       ws.path_seg, i_begin, i_end);
   else
-    hipLaunchKernelGGL((k_fast_paths<false>), dim3(cdiv((size_t)f.h * PATH_LANES, 64)), dim3(64), 0, stream, f, ws.pelev, ws.plen, ws.npath);
+    hipLaunchKernelGGL((k_fast_paths<false>), dim3(cdiv((size_t)f.h * PATH_LANES, 64)), dim3(64), 0, stream, f, ws.pelev, ws.plen, ws.npath,
+                       ws.path_seg, i_begin, i_end);
 }
 
 } // namespace atmrt

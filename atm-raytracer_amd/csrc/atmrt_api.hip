@@ -62,6 +62,8 @@ struct atmrt_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev[10] = {};
   hipEvent_t ev_seg[FAST_SEGMENTS] = {}; // a path segment is integrated (stream2) -> its intersect scan may start
+  hipEvent_t ev_scan[2 * FAST_SEGMENTS] = {}; // begin / end of every scan segment (after its wait), for intersect_ms
+  int scan_segments = 0;                       // segments of the last pipelined frame (0: ev[4]..ev[5] time the scan)
   atmrt_timings_t timings{};
   std::string error;
 
@@ -255,6 +257,13 @@ extern "C" int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal) {
       return create_fail(ATMRT_ERR_HIP, msg);
     }
   }
+  for (hipEvent_t& ev : c->ev_scan) {
+    if ((e = hipEventCreate(&ev)) != hipSuccess) {
+      std::string msg = std::string("hipEventCreate: ") + hipGetErrorString(e);
+      atmrt_ctx_destroy(c);
+      return create_fail(ATMRT_ERR_HIP, msg);
+    }
+  }
   for (hipEvent_t& ev : c->ev) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) {
       std::string msg = std::string("hipEventCreate: ") + hipGetErrorString(e);
@@ -282,6 +291,8 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_seg)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ev_scan)
     if (ev) (void)hipEventDestroy(ev);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -752,7 +763,7 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (fast) {
-    launch_fast_pipeline(f, ws, dense, s, c->stream2, c->ev_fork, c->ev_seg, ev); // records ev[0..4]
+    c->scan_segments = launch_fast_pipeline(f, ws, dense, s, c->stream2, c->ev_fork, c->ev_seg, c->ev_scan, ev); // records ev[0..4]
     HIP_TRY(c, hipEventRecord(ev[5], s));
     if (f.opaque) launch_fast_finalize(f, ws, dense, s);
     HIP_TRY(c, hipEventRecord(ev[6], s));
@@ -920,6 +931,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   hipEvent_t* ev = c->ev;
   const bool fast = f.p.generator == ATMRT_GEN_FAST;
   HIP_TRY(c, hipEventRecord(c->ev_t0, s));
+  c->scan_segments = 0;
   HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint64_t), s));
   PackedHits packed{};
   int rc;
@@ -944,6 +956,13 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
       t.paths_ms = v;
       HIP_TRY(c, hipEventElapsedTime(&v, ev[4], ev[5]));
       t.intersect_ms = v;
+      if (c->scan_segments) { // pipelined frame: the scan's own time, without the waits for the path segments
+        t.intersect_ms = 0.0;
+        for (int k = 0; k < c->scan_segments; k++) {
+          HIP_TRY(c, hipEventElapsedTime(&v, c->ev_scan[2 * k], c->ev_scan[2 * k + 1]));
+          t.intersect_ms += v;
+        }
+      }
     } else {
       HIP_TRY(c, hipEventElapsedTime(&v, ev[4], ev[5]));
       t.march_ms = v;

@@ -158,8 +158,8 @@ void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
                        hipStream_t stream);
 void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream, int i_begin, int i_end); // atmrt_paths.hip
 constexpr int FAST_SEGMENTS = 4;
-void launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
-                          hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* timing);
+int launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
+                         hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* ev_scan, hipEvent_t* timing); // returns the number of segments
 void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,
                         hipEvent_t ev_join, hipEvent_t* timing /* [0..1] phase A, [2..3] phase B */);
 void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);

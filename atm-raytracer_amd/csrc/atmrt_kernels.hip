@@ -1172,8 +1172,8 @@ void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out
 // headline size on a tenth of the chip) and the intersect scan only ever needs the samples integrated so far: the paths are
 // integrated in FAST_SEGMENTS pieces on the second stream and the scan of piece k (main stream, after the terrain profile)
 // waits for piece k alone, so it overlaps the integration of piece k + 1.  timing[4] is recorded before the first scan.
-void launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
-                          hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* timing) {
+int launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
+                         hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* ev_scan, hipEvent_t* timing) {
   const int cap = f.n_path_cap;
   const int nseg = cap >= 256 ? FAST_SEGMENTS : 1;
   int per = (cap - 1 + nseg - 1) / nseg;
@@ -1197,8 +1197,11 @@ void launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out,
   for (int k = 0; k < nseg; k++) {
     const int b0 = 1 + k * per, b1 = k == nseg - 1 ? cap : (b0 + per < cap ? b0 + per : cap);
     (void)hipStreamWaitEvent(stream, ev_seg[k], 0);
+    (void)hipEventRecord(ev_scan[2 * k], stream); // stamped once the wait is over
     launch_fast_intersect_segment(f, ws, out, stream, b0, b1, k == nseg - 1 ? 1 : 0);
+    (void)hipEventRecord(ev_scan[2 * k + 1], stream);
   }
+  return nseg;
 }
 
 void launch_fast_finalize(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {

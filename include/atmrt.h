@@ -256,7 +256,7 @@ typedef struct atmrt_timings {
   double total_ms;     /* first launch to last launch of the call */
   double profile_ms;   /* Fast phase A: k_fast_columns + k_terrain_profile   (utils.rs:176-199) */
   double paths_ms;     /* Fast phase B: k_fast_paths, concurrent with phase A (utils.rs:136-174) */
-  double intersect_ms; /* Fast phase C: k_fast_intersect, first launch to last; its segments wait for the path segments of phase B, so this interval overlaps paths_ms (utils.rs:201-289) */
+  double intersect_ms; /* Fast phase C: k_fast_intersect, summed over its segments (they run while later path segments of phase B are integrated) (utils.rs:201-289) */
   double march_ms;     /* Rectilinear: k_rect_march                           (rectilinear.rs:161-185) */
   double finalize_ms;  /* trace-point epilogue: k_fast_finalize / k_rect_finalize */
   double pack_ms;      /* scan + packing / multi-hit fill, when requested */

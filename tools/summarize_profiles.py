@@ -62,25 +62,38 @@ def main():
     fetch, nf = counters(os.path.join(src, "fetch"))
     write, nw = counters(os.path.join(src, "write"))
     hbm = {}
+    gen_frames = {}
+    for gen in ("Rectilinear", "Fast"):
+        q = os.path.join(src, f"bench_fetch_{gen}.json")
+        if os.path.exists(q) and bench_line(q):
+            gen_frames[gen] = bench_line(q)["steps"] + bench_line(q)["warmup"]
     for k in sorted(set(fetch) | set(write)):
         f_kb, w_kb = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
         hbm[k] = {"FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
                   "hbm_bytes_per_launch_raw": (f_kb + w_kb) * 1024.0, "hbm_bytes_per_launch_fetch_x2": (2.0 * f_kb + w_kb) * 1024.0,
                   "launches_FETCH_SIZE": nf.get(k, 0), "launches_WRITE_SIZE": nw.get(k, 0)}
+        frames = gen_frames.get("Rectilinear" if "k_rect" in k else "Fast")
+        if frames:  # kernels launched in segments: traffic of one frame
+            per_frame = nf.get(k, 0) / frames
+            hbm[k]["launches_per_frame"] = per_frame
+            hbm[k]["hbm_bytes_per_frame_fetch_x2"] = hbm[k]["hbm_bytes_per_launch_fetch_x2"] * per_frame
     if hbm:
         for p in (os.path.join(dst, f"pmc_hbm_summary_{tag}.json"), os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_hbm_latest.json")):
             json.dump(hbm, open(p, "w"), indent=1, sort_keys=True)
 
     sq = defaultdict(dict)
+    sq_launches = {}
     for sub in ("sq1", "sq2"):
-        c, _ = counters(os.path.join(src, sub))
+        c, nl = counters(os.path.join(src, sub))
         for k, v in c.items():
             sq[k].update(v)
-    steps = {}
+            sq_launches[k] = nl.get(k, 0)
+    steps, frames = {}, {}
     for gen, frag in (("Rectilinear", "k_rect_march"), ("Fast", "k_fast_intersect")):
         p = os.path.join(src, f"bench_sq1_{gen}.json")
         if os.path.exists(p) and bench_line(p):
             steps[frag] = bench_line(p)["ray_steps_per_frame"]
+            frames[frag] = bench_line(p)["steps"] + bench_line(p)["warmup"]
     for k, v in sq.items():
         if "GRBM_GUI_ACTIVE" in v and "SQ_ACTIVE_INST_VALU" in v:
             v["kernel_cycles"] = v["GRBM_GUI_ACTIVE"] / N_XCD
@@ -89,7 +102,9 @@ def main():
             v["lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
         for frag, n in steps.items():
             if frag in k and "SQ_INSTS_VALU" in v and "lane_utilisation" in v and ("march<0" in k or "intersect<8, 0" in k):
-                v["valu_lane_instructions_per_ray_step"] = v["SQ_INSTS_VALU"] * 64.0 * v["lane_utilisation"] / n
+                per_frame = sq_launches.get(k, 0) / frames[frag] if frames.get(frag) else 1.0  # a kernel launched in segments
+                v["launches_per_frame"] = per_frame
+                v["valu_lane_instructions_per_ray_step"] = v["SQ_INSTS_VALU"] * per_frame * 64.0 * v["lane_utilisation"] / n
     if sq:
         json.dump(sq, open(os.path.join(dst, f"sq_counters_{tag}.json"), "w"), indent=1, sort_keys=True)
     print(f"kernels: hbm {len(hbm)}, sq {len(sq)}; written to {dst} with tag {tag}")

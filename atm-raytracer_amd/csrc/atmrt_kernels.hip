@@ -905,7 +905,11 @@ static __device__ bool interp_group(const LatticeResult& lr, const uint64_t* mem
 }
 
 // interpolate :395-418 with collect_trace_points :213-243 and match_sequence :245-265
-template <bool FILL>
+// CAP = 4: the pixels whose four lattice corners hold at most four trace points together (nearly all of them) — the member
+// arrays are four registers wide; CAP = INTERP_MEMBERS: the others.  Both instances run over the whole image, each pixel is
+// blended by exactly one of them; the CAP = 4 instance also writes what does not depend on the members (referenced marks,
+// blended angles).
+template <bool FILL, int CAP>
 __global__ __launch_bounds__(256) void k_interp_blend(Frame f, InterpBuffers ib, LatticeResult lr, DensePlanes out,
                                                       const uint64_t* __restrict__ hit_offset, PackedHits packed,
                                                       unsigned long long* __restrict__ counters) {
@@ -918,16 +922,30 @@ __global__ __launch_bounds__(256) void k_interp_blend(Frame f, InterpBuffers ib,
   size_t corner[4]; // SEQUENCE = (0,0) (0,1) (1,0) (1,1): (elev_index + i, dir_index + j)
   for (int s = 0; s < 4; s++)
     corner[s] = (size_t)(ib.key_e[p] + (s >> 1) - f.ei0) * lr.nd + (size_t)(ib.key_d[p] + (s & 1) - f.di0);
-  uint64_t member_k[INTERP_MEMBERS];
-  double member_dist[INTERP_MEMBERS];
-  uint8_t member_corner[INTERP_MEMBERS], member_tag[INTERP_MEMBERS], member_group[INTERP_MEMBERS];
+  uint32_t total = 0;
+  for (int c = 0; c < 4; c++) {
+    if (!FILL && CAP == 4) ib.referenced[corner[c]] = 1;
+    total += lr.hit_count[corner[c]];
+  }
+  if (!FILL && CAP == 4) {
+    double e0 = lr.elevation_angle[corner[0]], e1 = lr.elevation_angle[corner[1]], e2 = lr.elevation_angle[corner[2]],
+           e3 = lr.elevation_angle[corner[3]];
+    double a0 = lr.azimuth[corner[0]], a1 = lr.azimuth[corner[1]], a2 = lr.azimuth[corner[2]], a3 = lr.azimuth[corner[3]];
+    out.elevation_angle[p] = e0 * (1.0 - rem_elev) * (1.0 - rem_dir) + e1 * (1.0 - rem_elev) * rem_dir +
+                             e2 * rem_elev * (1.0 - rem_dir) + e3 * rem_elev * rem_dir;
+    out.azimuth[p] = a0 * (1.0 - rem_elev) * (1.0 - rem_dir) + a1 * (1.0 - rem_elev) * rem_dir + a2 * rem_elev * (1.0 - rem_dir) +
+                     a3 * rem_elev * rem_dir;
+  }
+  if ((CAP == 4) != (total <= 4u)) return; // the other instance's pixel
+  uint64_t member_k[CAP];
+  double member_dist[CAP];
+  uint8_t member_corner[CAP], member_tag[CAP], member_group[CAP];
   int n_members = 0, n_groups = 0;
   for (int c = 0; c < 4; c++) {
-    if (!FILL) ib.referenced[corner[c]] = 1;
     uint64_t k0 = lr.hit_offset[corner[c]];
     uint32_t cnt = lr.hit_count[corner[c]];
     for (uint32_t q = 0; q < cnt; q++) {
-      if (n_members >= INTERP_MEMBERS) {
+      if (n_members >= CAP) {
         atomicOr(&counters[2], 4ull);
         break;
       }
@@ -961,16 +979,7 @@ __global__ __launch_bounds__(256) void k_interp_blend(Frame f, InterpBuffers ib,
       count++;
     }
   }
-  if (!FILL) {
-    out.hit_count[p] = count;
-    double e0 = lr.elevation_angle[corner[0]], e1 = lr.elevation_angle[corner[1]], e2 = lr.elevation_angle[corner[2]],
-           e3 = lr.elevation_angle[corner[3]];
-    double a0 = lr.azimuth[corner[0]], a1 = lr.azimuth[corner[1]], a2 = lr.azimuth[corner[2]], a3 = lr.azimuth[corner[3]];
-    out.elevation_angle[p] = e0 * (1.0 - rem_elev) * (1.0 - rem_dir) + e1 * (1.0 - rem_elev) * rem_dir +
-                             e2 * rem_elev * (1.0 - rem_dir) + e3 * rem_elev * rem_dir;
-    out.azimuth[p] = a0 * (1.0 - rem_elev) * (1.0 - rem_dir) + a1 * (1.0 - rem_elev) * rem_dir + a2 * rem_elev * (1.0 - rem_dir) +
-                     a3 * rem_elev * rem_dir;
-  }
+  if (!FILL) out.hit_count[p] = count;
 }
 
 // ray-steps of the lattice pixels the image actually references (the reference memoises exactly those); grid-stride,
@@ -1005,12 +1014,17 @@ void launch_lattice_keys(const Frame& f, const InterpBuffers& ib, double min_ele
 void launch_interp_blend(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,
                          const DensePlanes& dense, const PackedHits& packed, hipStream_t stream) {
   dim3 grid(cdiv(f.wl, 256), f.h);
-  if (fill)
-    hipLaunchKernelGGL((k_interp_blend<true>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
+  if (fill) {
+    hipLaunchKernelGGL((k_interp_blend<true, 4>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
                        (unsigned long long*)ws.counters);
-  else
-    hipLaunchKernelGGL((k_interp_blend<false>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr, packed,
+    hipLaunchKernelGGL((k_interp_blend<true, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
                        (unsigned long long*)ws.counters);
+  } else {
+    hipLaunchKernelGGL((k_interp_blend<false, 4>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr, packed,
+                       (unsigned long long*)ws.counters);
+    hipLaunchKernelGGL((k_interp_blend<false, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr,
+                       packed, (unsigned long long*)ws.counters);
+  }
 }
 void launch_interp_finish(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr,
                           const DensePlanes& dense, const PackedHits& packed, hipStream_t stream) {

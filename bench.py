@@ -230,7 +230,7 @@ def main():
                "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
                "all_kernels": {per_kernel[k][0]: {"ms": mean(k), "algorithmic_GBps": per_kernel[k][1] / (mean(k) * 1e-3) / 1e9}
                                for k in keys if mean(k) > 0}}
-        sq_file = os.path.join(ROOT, "profiles", "r01", "sq_counters_v8.json")
+        sq_file = os.path.join(ROOT, "profiles", "r01", "sq_counters_v9.json")
         if os.path.exists(sq_file):
             # the compute side of the roofline, from the committed rocprofv3 SQ-counter passes of this command: fraction of
             # cycles the SIMDs' VALU pipes are busy (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles) and active lanes
@@ -244,7 +244,7 @@ def main():
                                    "lane_instructions_per_s": (ipr * steps_per_launch / (ms * 1e-3)) if ipr else None,
                                    "fp64_issue_peak_per_s": FP64_ISSUE_PEAK,
                                    "frac_of_fp64_issue_peak": (ipr * steps_per_launch / (ms * 1e-3) / FP64_ISSUE_PEAK) if ipr else None,
-                                   "source": "profiles/r01/sq_counters_v8.json",
+                                   "source": "profiles/r01/sq_counters_v9.json",
                                    "note": "k_rect_march is FP64-issue bound (12 n(h) evaluations per RK4 step, each a pow and a Ciddor compressibility term), not HBM bound"}
         return out
 

@@ -649,7 +649,7 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   if (f.p.generator == ATMRT_GEN_RECTILINEAR) HIP_TRY(c, c->d_rect_rec.reserve(4 * npx * sizeof(double)));
   ws->rect_rec = c->d_rect_rec.as<double>();
   ws->slot_packed = PackedHits{};
-  if ((f.p.generator == ATMRT_GEN_RECTILINEAR && !f.opaque) || f.n_objects > 0) { // slots of the counting march / trace passes
+  if (!f.opaque || f.n_objects > 0) { // slots of the counting march / scan / trace passes
     HIP_TRY(c, c->d_slot_step.reserve((size_t)RECT_SLOTS * npx * sizeof(uint32_t)));
     if (f.p.generator == ATMRT_GEN_RECTILINEAR) HIP_TRY(c, c->d_slot_rec.reserve(4 * (size_t)RECT_SLOTS * npx * sizeof(double)));
     if (f.n_objects > 0) {

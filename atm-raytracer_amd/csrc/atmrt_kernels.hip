@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
                                                         uint32_t* __restrict__ hit_count,
                                                         uint32_t* __restrict__ px_steps,
                                                         unsigned long long* __restrict__ counters, double* __restrict__ dprev_state,
-                                                        int i_begin, int i_end, int last_segment) {
+                                                        int i_begin, int i_end, int last_segment, uint32_t* __restrict__ slot_step) {
   // Samples i_begin .. i_end - 1 (the frame is scanned in the segments in which its ray paths are integrated, so that the scan
   // of one segment overlaps the integration of the next); between segments a pixel's state is the difference at its last
   // sample (dprev_state), its first hit (hit_step) and its count (hit_count).
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
   const int y0 = (blockIdx.y * 4 + wave) * RR;
   const int cap = f.n_path_cap;
   const size_t wl = (size_t)f.wl;
+  const size_t plane_px = wl * (size_t)f.h;
   if (y0 >= f.h) return;
 
   // rows past the image repeat the last row (identical work, never stored), so the fast loop stays uniform
@@ -154,6 +155,8 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
       double p[CH];
 #pragma unroll
       for (int k = 0; k < CH; k++) p[k] = pr[k];
+      unsigned hitbits = 0;
+      const unsigned cnt0 = cnt[r];
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         const double d = p[k] - t[k];
@@ -161,8 +164,17 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
         const bool nh = hit && first[r] < 0;
         first[r] = nh ? i + k - 1 : first[r];
         if (MODE == 0) nfound += nh ? 1 : 0;
-        else cnt[r] += hit ? 1u : 0u;
+        else {
+          cnt[r] += hit ? 1u : 0u;
+          hitbits |= hit ? 1u << k : 0u;
+        }
         dprev[r] = d;
+      }
+      if (MODE != 0 && hitbits && xok && y0 + r < f.h) { // rare: keep the first RECT_SLOTS crossings of the pixel for the list
+        unsigned c = cnt0;
+        const size_t pp = (size_t)(y0 + r) * wl + x;
+        for (unsigned hb = hitbits; hb && c < (unsigned)RECT_SLOTS; hb &= hb - 1, c++)
+          slot_step[(size_t)c * plane_px + pp] = (uint32_t)(i + __builtin_ctz(hb) - 1);
       }
     }
     if (MODE == 0 && __all(nfound == RR)) {
@@ -180,7 +192,11 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
           const bool hit = dprev[r] * d < 0.0;
           const bool nh = hit && first[r] < 0;
           first[r] = nh ? i - 1 : first[r];
-          if (MODE != 0) cnt[r] += hit ? 1u : 0u;
+          if (MODE != 0 && hit) {
+            if (cnt[r] < (unsigned)RECT_SLOTS && xok && y0 + r < f.h)
+              slot_step[(size_t)cnt[r] * plane_px + (size_t)(y0 + r) * wl + x] = (uint32_t)(i - 1);
+            cnt[r]++;
+          }
           dprev[r] = d;
         }
       }
@@ -260,11 +276,29 @@ __global__ __launch_bounds__(256) void k_fast_finalize(Frame f, const DirCalc* _
   store_dense(out, p, plane, fast_hit(f, earth_for<CALC>(f), c, prof, pelev, plen, x, y, s));
 }
 
-// terrain_alpha < 1: second scan that lists every sign change of every pixel (step index + pixel)
+// terrain_alpha < 1: the list of every sign change of every pixel (step index + pixel).  The counting scan kept the first
+// RECT_SLOTS crossings of each pixel; k_fast_gather_steps moves those, and only pixels with more are scanned a second time.
+__global__ __launch_bounds__(256) void k_fast_gather_steps(Frame f, const uint32_t* __restrict__ hit_count,
+                                                           const uint64_t* __restrict__ hit_offset,
+                                                           const uint32_t* __restrict__ slot_step, uint32_t* __restrict__ list_step,
+                                                           uint32_t* __restrict__ list_pixel) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const uint32_t n = hit_count[p];
+  if (n > (uint32_t)RECT_SLOTS) return;
+  const uint64_t k = hit_offset[p];
+  for (uint32_t j = 0; j < n; j++) {
+    list_step[k + j] = slot_step[(size_t)j * plane + p];
+    list_pixel[k + j] = (uint32_t)p;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fast_list(Frame f, const double* __restrict__ prof,
                                                    const double* __restrict__ pelev,
                                                    const int32_t* __restrict__ npath,
                                                    const uint64_t* __restrict__ hit_offset,
+                                                   const uint32_t* __restrict__ hit_count,
                                                    uint32_t* __restrict__ list_step,
                                                    uint32_t* __restrict__ list_pixel) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,6 +307,7 @@ __global__ __launch_bounds__(256) void k_fast_list(Frame f, const double* __rest
   int n = npath[y];
   n = n < f.n_t ? n : f.n_t;
   size_t p = (size_t)y * f.wl + x;
+  if (hit_count[p] <= (uint32_t)RECT_SLOTS) return; // listed from the slots of the counting scan (k_fast_gather_steps)
   uint64_t k = hit_offset[p];
   const double* row = pelev + (size_t)y * f.n_path_cap;
   double dprev = row[0] - prof[x];
@@ -1172,10 +1207,12 @@ static void launch_fast_intersect_segment(const Frame& f, Workspace& ws, const D
   dim3 grid(cdiv(f.wl, 64), cdiv(f.h, 4 * FAST_RR));
   if (f.opaque)
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 0>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last);
+                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last,
+                       (uint32_t*)nullptr);
   else
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 1>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last);
+                       ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last,
+                       ws.slot_step);
 }
 
 void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
@@ -1259,8 +1296,10 @@ void launch_pack_first_hits(const Frame& f, Workspace& ws, const DensePlanes& de
 
 void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense,
                             const PackedHits& packed, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fast_gather_steps, dim3(cdiv((size_t)f.wl * f.h, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count,
+                     ws.hit_offset, ws.slot_step, ws.list_step, ws.list_pixel);
   hipLaunchKernelGGL(k_fast_list, dim3(cdiv(f.wl, 256), f.h), dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
-                     ws.hit_offset, ws.list_step, ws.list_pixel);
+                     ws.hit_offset, (const uint32_t*)dense.hit_count, ws.list_step, ws.list_pixel);
   if (n_hits)
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                           stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,

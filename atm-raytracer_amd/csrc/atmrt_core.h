@@ -381,13 +381,9 @@ template <bool CUBIC>
 ATMRT_HD double refr_n_hint(const AtmTable& a, double h, int& hint) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int ku = __builtin_amdgcn_readfirstlane(hint);
-  // the table is read-only for the whole launch: through the constant address space these are scalar loads
-  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
-  const ConstTable ka = (ConstTable)(uintptr_t)&a;
-  const bool ok = (ku == 0 || h >= ka->from[ku]) && (ku == ka->n - 1 || h < ka->from[ku + 1]);
+  const bool ok = (ku == 0 || h >= a.from[ku]) && (ku == a.n - 1 || h < a.from[ku + 1]);
   if (__all(ok))
-    return refr_n_layer<CUBIC>(ka->k_refr, ka->cubic[ku], ka->hb[ku], ka->tb[ku], ka->pb[ku], ka->lapse[ku], ka->c2[ku], ka->c3[ku],
-                               ka->expo[ku], h);
+    return refr_n_layer<CUBIC>(a.k_refr, a.cubic[ku], a.hb[ku], a.tb[ku], a.pb[ku], a.lapse[ku], a.c2[ku], a.c3[ku], a.expo[ku], h);
   const int k = ok ? ku : atm_layer(a, h);
   hint = k;
   return refr_n_layer<CUBIC>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);

@@ -125,6 +125,10 @@ class Timings(C.Structure):
                 ("n_hits", C.c_uint64)]
 
 
+class FrameStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("unlisted_rays", "unlisted_columns", "retraced_pixels", "big_steps", "big_blend_pixels")]
+
+
 def result_to_numpy(res):
     """Copy an atmrt_result_t (library-owned) into a dict of numpy arrays."""
     import numpy as np

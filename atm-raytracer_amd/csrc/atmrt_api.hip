@@ -65,6 +65,7 @@ struct atmrt_ctx {
   hipEvent_t ev_scan[2 * FAST_SEGMENTS] = {}; // begin / end of every scan segment (after its wait), for intersect_ms
   int scan_segments = 0;                       // segments of the last pipelined frame (0: ev[4]..ev[5] time the scan)
   atmrt_timings_t timings{};
+  atmrt_frame_stats_t stats{};
   std::string error;
 
   // terrain (Terrain, terrain/mod.rs:55-57): tiles keyed by integer degrees
@@ -208,6 +209,10 @@ extern "C" size_t atmrt_abi_sizeof(int which) {
     case 5: return sizeof(atmrt_earth_model_t);
     case 6: return sizeof(atmrt_position_t);
     case 7: return sizeof(atmrt_frame_t);
+    case 8: return sizeof(atmrt_frame_stats_t);
+    case 9: return sizeof(atmrt_timings_t);
+    case 10: return sizeof(atmrt_coloring_t);
+    case 11: return sizeof(atmrt_device_hits_t);
     default: return 0;
   }
 }
@@ -357,6 +362,7 @@ extern "C" int atmrt_terrain_load_dir(atmrt_ctx* c, const char* path, int32_t* n
     }
     if (rc) {
       closedir(d);
+      c->terrain_dirty = true; // tiles read before the bad file are in the map: the mosaic must be rebuilt to match it
       return c->fail(rc, "%s", msg.c_str());
     }
     c->tiles[{lat0, lon0}] = std::move(t);
@@ -620,7 +626,7 @@ static size_t packed_bytes(size_t n);
 
 static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   size_t npx = (size_t)f.wl * f.h;
-  HIP_TRY(c, c->d_counters.reserve(4 * sizeof(uint64_t)));
+  HIP_TRY(c, c->d_counters.reserve(N_COUNTERS * sizeof(uint64_t)));
   HIP_TRY(c, c->d_hit_step.reserve(npx * sizeof(int32_t)));
   HIP_TRY(c, c->d_hit_offset.reserve(npx * sizeof(uint64_t)));
   size_t nsamples = f.n_objects && f.p.generator != ATMRT_GEN_RECTILINEAR ? (size_t)f.n_t * f.wl : 0;
@@ -930,15 +936,19 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   hipStream_t s = c->stream;
   hipEvent_t* ev = c->ev;
   const bool fast = f.p.generator == ATMRT_GEN_FAST;
+  // the buffers of the previous frame are about to be reused (or reallocated): until this frame has succeeded there is nothing
+  // atmrt_draw_image / atmrt_last_hits_device may touch
+  c->last_valid = false;
+  c->stats = atmrt_frame_stats_t{};
   HIP_TRY(c, hipEventRecord(c->ev_t0, s));
   c->scan_segments = 0;
-  HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint64_t), s));
+  HIP_TRY(c, hipMemsetAsync(ws.counters, 0, N_COUNTERS * sizeof(uint64_t), s));
   PackedHits packed{};
   int rc;
   if (f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR) rc = run_interpolating(c, f, ws, dense, &packed, n_hits_out);
   else rc = run_core(c, f, ws, dense, want_packed, &packed, n_hits_out);
   if (rc) return rc;
-  uint64_t counters[4] = {0, 0, 0, 0};
+  uint64_t counters[N_COUNTERS] = {};
   HIP_TRY(c, hipEventRecord(c->ev_t1, s));
   HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -980,6 +990,11 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step "
                    "or more than %d trace points in four lattice corners",
                    (unsigned long long)counters[2], 12, 64);
+  c->stats.unlisted_rays = counters[4];
+  c->stats.unlisted_columns = counters[5];
+  c->stats.big_steps = counters[6];
+  c->stats.big_blend_pixels += counters[7];
+  c->stats.retraced_pixels += ws.n_overflow;
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;
@@ -1188,6 +1203,12 @@ extern "C" int atmrt_last_timings(atmrt_ctx* c, atmrt_timings_t* out) {
   return ATMRT_OK;
 }
 
+extern "C" int atmrt_last_stats(atmrt_ctx* c, atmrt_frame_stats_t* out) {
+  if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
+  *out = c->stats;
+  return ATMRT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // renderer compositing + colouring
 // ---------------------------------------------------------------------------------------------
@@ -1219,6 +1240,7 @@ extern "C" int atmrt_draw_image_device(atmrt_ctx* c, const atmrt_coloring_t* col
 extern "C" int atmrt_draw_image(atmrt_ctx* c, const atmrt_coloring_t* coloring, uint8_t* rgb) {
   if (!c || !coloring || !rgb) return ATMRT_ERR_INVALID_ARGUMENT;
   if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_draw_image needs a frame: call atmrt_generate first");
+  HIP_TRY(c, hipSetDevice(c->device)); // the staging buffer must live on this context's device
   HIP_TRY(c, c->d_io.reserve(3 * c->last_npx + 256));
   int rc = atmrt_draw_image_device(c, coloring, c->d_io.as<uint8_t>());
   if (rc) return rc;
@@ -1317,6 +1339,22 @@ extern "C" int atmrt_coords_at_dist(atmrt_ctx* c, double lat0, double lon0, doub
   launch_coords_at_dist(f, lat0, lon0, dir_deg, n, d, d + n, d + 2 * n, c->stream);
   HIP_TRY(c, hipMemcpyAsync(lat, d + n, n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(lon, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_math_probe(atmrt_ctx* c, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1) {
+  if (!c || (n && (!a || !out0)) || op < 0 || op > ATMRT_PROBE_POW3) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!n) return ATMRT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->d_io.reserve(4 * n * 8));
+  double* d = c->d_io.as<double>();
+  HIP_TRY(c, hipMemcpyAsync(d, a, n * 8, hipMemcpyHostToDevice, c->stream));
+  if (b) HIP_TRY(c, hipMemcpyAsync(d + n, b, n * 8, hipMemcpyHostToDevice, c->stream));
+  launch_math_probe(op, n, d, b ? d + n : nullptr, d + 2 * n, d + 3 * n, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(out0, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (out1) HIP_TRY(c, hipMemcpyAsync(out1, d + 3 * n, n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   return ATMRT_OK;

@@ -76,6 +76,12 @@ struct PathSegState {
   int32_t hint, n, done, n_final;
 };
 
+// Device counters of a frame (Workspace::counters): [0] ray-steps, [1] total of the last scan (trace points), [2] error flags,
+// [3] scan total of the close lists / pixels that overflowed their slots / cursor of the overflow list, [4] rays whose candidate
+// list overflowed, [5] columns whose candidate list overflowed, [6] steps with more trace points than StepHits holds,
+// [7] InterpolatingRectilinear pixels with more corner points than the in-register member list
+constexpr int N_COUNTERS = 8;
+
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
 constexpr int RECT_SLOTS = 4;
@@ -192,6 +198,7 @@ void launch_ray_paths(const Frame& f, double h0, size_t n_angles, const double* 
                       size_t n_steps, double* x, double* h, hipStream_t stream);
 void launch_atm_sample(const Frame& f, size_t n, const double* alt, double* t, double* p, double* nidx, double* dn,
                        hipStream_t stream);
+void launch_math_probe(int op, size_t n, const double* a, const double* b, double* out0, double* out1, hipStream_t stream);
 void launch_coords_at_dist(const Frame& f, double lat0, double lon0, double dir, size_t n, const double* dist,
                            double* lat, double* lon, hipStream_t stream);
 

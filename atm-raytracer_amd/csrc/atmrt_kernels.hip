@@ -54,12 +54,13 @@ template <int CALC, bool STORE_LL>
 __global__ __launch_bounds__(256) void k_terrain_profile(Frame f, const DirCalc* __restrict__ colcalc,
                                                          double* __restrict__ prof, double* __restrict__ plat,
                                                          double* __restrict__ plon) {
-  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  // sample blocks on grid.x (up to 4e6 / 16 of them), column tiles on grid.y (at most 1024): grid.y is limited to 65535
+  int x = blockIdx.y * 64 + (threadIdx.x & 63);
   int sub = threadIdx.x >> 6;
   if (x >= f.wl) return;
   const Earth e = earth_for<CALC>(f);
   const DirCalc c = colcalc[x];
-  int i0 = blockIdx.y * PROFILE_SAMPLES_PER_BLOCK;
+  int i0 = blockIdx.x * PROFILE_SAMPLES_PER_BLOCK;
   for (int k = sub; k < PROFILE_SAMPLES_PER_BLOCK; k += 4) {
     int i = i0 + k;
     if (i >= f.n_t) break;
@@ -374,13 +375,14 @@ __global__ __launch_bounds__(256) void k_dense_from_packed(Frame f, const uint64
 constexpr int COL_CAND = 64;
 template <int CALC>
 __global__ __launch_bounds__(64) void k_column_candidates(Frame f, const DirCalc* __restrict__ colcalc, int32_t* __restrict__ ccand,
-                                                          int32_t* __restrict__ ncand) {
+                                                          int32_t* __restrict__ ncand, unsigned long long* __restrict__ counters) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= f.wl) return;
   int cand[COL_CAND];
   int n = 0;
   const bool ok = ray_candidates<CALC, COL_CAND>(f, f.earth, colcalc[x], cand, n);
   ncand[x] = ok ? n : -1;
+  if (!ok && n == COL_CAND) atomicAdd(&counters[5], 1ull); // statistics only (atmrt_last_stats)
   if (ok)
     for (int q = 0; q < n; q++) ccand[(size_t)x * COL_CAND + q] = cand[q];
 }
@@ -1168,6 +1170,42 @@ __global__ void k_coords_at_dist(Frame f, double lat0, double lon0, double dir, 
   coords_at_dist(f.earth, c, dist[i], lat[i], lon[i]);
 }
 
+// detmath.h element-wise (atmrt_math_probe): the GPU's instruction sequences against the host's on arbitrary operands
+__global__ void k_math_probe(int op, size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                             double* __restrict__ out0, double* __restrict__ out1) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r0 = 0.0, r1 = 0.0;
+  switch (op) {
+    case ATMRT_PROBE_DIV: r0 = dm_div(x, y); break;
+    case ATMRT_PROBE_DIV_R: r0 = dm_div_r(x, y, 1.0 / y); break;
+    case ATMRT_PROBE_SQRT_INRANGE: r0 = dm_sqrt_inrange(x); break;
+    case ATMRT_PROBE_EXP: r0 = dm_exp(x); break;
+    case ATMRT_PROBE_LOG: r0 = dm_log(x); break;
+    case ATMRT_PROBE_POW: r0 = dm_pow(x, y); break;
+    case ATMRT_PROBE_SINCOS: dm_sincos(x, &r0, &r1); break;
+    case ATMRT_PROBE_ASIN: r0 = dm_asin(x); break;
+    case ATMRT_PROBE_ATAN2: r0 = dm_atan2(x, y); break;
+    case ATMRT_PROBE_IEEE_DIV: r0 = x / y; break;
+    case ATMRT_PROBE_IEEE_SQRT: r0 = dm_sqrt(x); break;
+    case ATMRT_PROBE_ATAN: r0 = dm_atan(x); break;
+    case ATMRT_PROBE_TAN: r0 = dm_tan(x); break;
+    case ATMRT_PROBE_POW3: { // the three-point form the stepping kernels use (wave votes on the range guards)
+      double p1, p2;
+      pow3(x, x * 0.99999981, x * 1.00000019, y, r0, p1, p2);
+      r1 = p1 + p2;
+      break;
+    }
+    default: break;
+  }
+  out0[i] = r0;
+  if (out1) out1[i] = r1;
+}
+void launch_math_probe(int op, size_t n, const double* a, const double* b, double* out0, double* out1, hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(k_math_probe, dim3(cdiv(n, 256)), dim3(256), 0, stream, op, n, a, b, out0, out1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -1191,11 +1229,11 @@ void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipSt
   hipLaunchKernelGGL(k_fast_columns, dim3(cdiv(f.wl, 256)), dim3(256), 0, stream, f, ws.colcalc);
   if (f.n_objects) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC, true>),
-                                                          dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)),
+                                                          dim3(cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK), cdiv(f.wl, 64)),
                                                           dim3(256), 0, stream, f, ws.colcalc, ws.prof, ws.plat, ws.plon));
   } else {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC, false>),
-                                                          dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)),
+                                                          dim3(cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK), cdiv(f.wl, 64)),
                                                           dim3(256), 0, stream, f, ws.colcalc, ws.prof, ws.plat, ws.plon));
   }
   (void)hipEventRecord(timing[1], stream);
@@ -1241,7 +1279,7 @@ int launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, 
   (void)hipEventRecord(timing[0], stream);
   hipLaunchKernelGGL(k_fast_columns, dim3(cdiv(f.wl, 256)), dim3(256), 0, stream, f, ws.colcalc);
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_terrain_profile<CALC, false>),
-                                                        dim3(cdiv(f.wl, 64), cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK)), dim3(256), 0,
+                                                        dim3(cdiv(f.n_t, PROFILE_SAMPLES_PER_BLOCK), cdiv(f.wl, 64)), dim3(256), 0,
                                                         stream, f, ws.colcalc, ws.prof, ws.plat, ws.plon));
   (void)hipEventRecord(timing[1], stream);
   (void)hipEventRecord(timing[4], stream);
@@ -1275,7 +1313,7 @@ void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count
 void launch_close_count(const Frame& f, Workspace& ws, hipStream_t stream) {
   size_t n = (size_t)f.n_t * f.wl;
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_column_candidates<CALC>), dim3(cdiv(f.wl, 64)), dim3(64), 0, stream, f,
-                                                        ws.colcalc, ws.col_cand, ws.col_ncand));
+                                                        ws.colcalc, ws.col_cand, ws.col_ncand, (unsigned long long*)ws.counters));
   hipLaunchKernelGGL((k_close_objects<false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.col_cand,
                      ws.col_ncand, ws.ccount, (const uint64_t*)nullptr, (uint32_t*)nullptr);
   // total number of list entries -> counters[3]

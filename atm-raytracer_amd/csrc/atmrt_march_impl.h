@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
       // candidates, or a DirectionalCalc without the pre-filter) test every object against both samples of a step.
       // x_wake: the first stepper distance at which any candidate can be close — before it the proximity filter is skipped.
       const bool use_cand = ray_candidates<CALC, CAND_CAP>(f, e, c, cand, ncand, clo, chi);
+      if (!FILL && !use_cand && ncand == CAND_CAP) atomicAdd(&counters[4], 1ull); // statistics only (atmrt_last_stats)
       unsigned m0 = use_cand ? close_mask(f, e, lat0, lon0, cand, ncand) : 0u, m1 = 0u;
       double x_wake = dm_inf();
       for (int q = 0; q < ncand; q++)

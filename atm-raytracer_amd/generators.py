@@ -172,6 +172,12 @@ class Generator:
         self.ctx.check(self.ctx.lib.atmrt_last_hits_device(self.ctx.handle, C.byref(pod), None))
         return t
 
+    def last_stats(self):
+        """atmrt_frame_stats_t of the last frame: how often it left the fast routes of the device path."""
+        t = _abi.FrameStats()
+        self.ctx.check(self.ctx.lib.atmrt_last_stats(self.ctx.handle, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _abi.FrameStats._fields_}
+
     def last_timings(self):
         t = _abi.Timings()
         self.ctx.check(self.ctx.lib.atmrt_last_timings(self.ctx.handle, C.byref(t)))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ATMRT_ABI_VERSION 2
+#define ATMRT_ABI_VERSION 3
 
 typedef enum atmrt_status {
   ATMRT_OK = 0,
@@ -265,6 +265,18 @@ typedef struct atmrt_timings {
 } atmrt_timings_t;
 int atmrt_last_timings(atmrt_ctx* ctx, atmrt_timings_t* out);
 
+/* How often the last frame left the fast routes of the device path (results are the same either way; tests use this to
+ * prove that a workload really exercises the fall-back routes). */
+typedef struct atmrt_frame_stats {
+  uint64_t unlisted_rays;     /* Rectilinear, scenes with objects: rays with more candidate objects than the per-ray list
+                                 holds (24) — they test every object at every sample (is_close, frustum.rs:103-114) */
+  uint64_t unlisted_columns;  /* Fast / InterpolatingRectilinear: columns with more candidates than the per-column list (64) */
+  uint64_t retraced_pixels;   /* Rectilinear: pixels with more trace points than the 4 slots of the counting march, marched again */
+  uint64_t big_steps;         /* steps that produced more trace points than the in-register step list (12): sorted in HBM */
+  uint64_t big_blend_pixels;  /* InterpolatingRectilinear: pixels whose four lattice corners hold more than 64 trace points */
+} atmrt_frame_stats_t;
+int atmrt_last_stats(atmrt_ctx* ctx, atmrt_frame_stats_t* out);
+
 /* ---- renderer compositing + colouring on the device (src/renderer/mod.rs:367-414, src/coloring) -- */
 typedef enum atmrt_coloring_kind { ATMRT_COLORING_SIMPLE = 0, ATMRT_COLORING_SHADING = 1 } atmrt_coloring_kind;
 typedef enum atmrt_palette { ATMRT_PALETTE_LEGACY = 0, ATMRT_PALETTE_IMPROVED = 1 } atmrt_palette;
@@ -301,6 +313,30 @@ int atmrt_atmosphere_sample(atmrt_ctx* ctx, size_t n, const double* altitude, do
 /* DirectionalCalc::coords_at_dist (directional_calc.rs:5-7) for the context's earth model. */
 int atmrt_coords_at_dist(atmrt_ctx* ctx, double lat0, double lon0, double dir_deg, size_t n, const double* dist,
                          double* lat, double* lon);
+
+/* The deterministic elementary functions of the device path (csrc/detmath.h), element-wise on host arrays: the same
+ * instruction sequences the marching kernels execute.  The bit-exactness claim of this library rests on them returning, on
+ * gfx950, exactly what the host build of detmath.h returns (and, for DIV / DIV_R / SQRT_INRANGE, what IEEE division and square
+ * root return inside their documented operand range); tests/test_gpu_detmath.py checks that on 1e7 operands per function.
+ * b may be NULL for one-operand functions, out1 may be NULL unless op is SINCOS or POW3. */
+typedef enum atmrt_math_probe_op {
+  ATMRT_PROBE_DIV = 0,          /* dm_div(a, b): division without the range scaling / fix-up steps */
+  ATMRT_PROBE_DIV_R = 1,        /* dm_div_r(a, b, RN(1/b)): division by a tabulated reciprocal */
+  ATMRT_PROBE_SQRT_INRANGE = 2, /* dm_sqrt_inrange(a) */
+  ATMRT_PROBE_EXP = 3,
+  ATMRT_PROBE_LOG = 4,
+  ATMRT_PROBE_POW = 5,          /* dm_pow(a, b) */
+  ATMRT_PROBE_SINCOS = 6,       /* out0 = sin, out1 = cos */
+  ATMRT_PROBE_ASIN = 7,
+  ATMRT_PROBE_ATAN2 = 8,        /* dm_atan2(a, b) */
+  ATMRT_PROBE_IEEE_DIV = 9,     /* the compiler's a / b */
+  ATMRT_PROBE_IEEE_SQRT = 10,   /* the compiler's sqrt(a) */
+  ATMRT_PROBE_ATAN = 11,
+  ATMRT_PROBE_TAN = 12,
+  ATMRT_PROBE_POW3 = 13         /* out0 = dm_pow(a, b) through the three-point form of the stepping kernels; out1 = sum of
+                                   the other two points (a * 0.99999981, a * 1.00000019) */
+} atmrt_math_probe_op;
+int atmrt_math_probe(atmrt_ctx* ctx, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1);
 
 #ifdef __cplusplus
 }

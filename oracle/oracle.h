@@ -103,6 +103,9 @@ ovec3 oracle_find_normal(const atmrt_earth_model_t* model, double lat, double lo
 int oracle_generate(const atmrt_params_t* params, const atmrt_atmosphere_t* atm, const oracle_terrain* terrain,
                     const atmrt_object_t* objects, size_t n_objects, int n_threads, atmrt_result_t* out);
 void oracle_result_free(atmrt_result_t* r);
+/* checker economy for full-size frames: only rows y % stride == phase are computed by the Fast and Rectilinear generators
+ * (the others are left without trace points); stride 1 restores the whole frame */
+void oracle_set_row_filter(int stride, int phase);
 
 /* ---- renderer compositing + colouring (src/renderer/mod.rs:367-414, src/coloring) ---- */
 int oracle_coloring_from_conf(const atmrt_params_t* p, int32_t kind, double water_level, double ambient_light, double light_zenith_angle,

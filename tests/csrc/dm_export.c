@@ -6,3 +6,14 @@ V1(sin) V1(cos) V1(tan) V1(asin) V1(atan) V1(exp) V1(log) V1(sqrt) V1(floor)
 void t_atan2(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_atan2(a[i], b[i]); }
 void t_pow(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_pow(a[i], b[i]); }
 void t_div_r_seq(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_div_r_seq(a[i], b[i], 1.0 / b[i]); }
+/* host counterparts of atmrt_math_probe (tests/test_gpu_detmath.py): on the host dm_div / dm_div_r / dm_sqrt_inrange ARE the IEEE operations */
+void t_div(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_div(a[i], b[i]); }
+void t_div_r(const double* a, const double* b, double* y, size_t n) { for (size_t i = 0; i < n; i++) y[i] = dm_div_r(a[i], b[i], 1.0 / b[i]); }
+V1(sqrt_inrange)
+void t_sincos(const double* x, double* s, double* c, size_t n) { for (size_t i = 0; i < n; i++) dm_sincos(x[i], &s[i], &c[i]); }
+void t_pow3(const double* a, const double* b, double* y0, double* y1, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    y0[i] = dm_pow(a[i], b[i]);
+    y1[i] = dm_pow(a[i] * 0.99999981, b[i]) + dm_pow(a[i] * 1.00000019, b[i]);
+  }
+}

@@ -51,6 +51,8 @@ class Oracle:
         L.oracle_generate.argtypes = [C.POINTER(_abi.Params), C.POINTER(_abi.Atmosphere), C.c_void_p,
                                       C.POINTER(_abi.Object), C.c_size_t, C.c_int, C.POINTER(_abi.Result)]
         L.oracle_result_free.argtypes = [C.POINTER(_abi.Result)]
+        L.oracle_set_row_filter.argtypes = [C.c_int, C.c_int]
+        L.oracle_set_row_filter.restype = None
         L.oracle_atm_compile.argtypes = [C.POINTER(_abi.Atmosphere), C.c_double, C.POINTER(EnvAtm)]
         for f in ("oracle_atm_temperature", "oracle_atm_pressure", "oracle_n", "oracle_dn"):
             getattr(L, f).argtypes = [C.POINTER(EnvAtm), C.c_double]
@@ -156,7 +158,8 @@ class Oracle:
         return tuple(np.array([v.x, v.y, v.z]) for v in (n, e, u))
 
     # ---- generators ----------------------------------------------------------------------
-    def generate(self, params, atm=None, terrain=None, objects=None, n_threads=0):
+    def generate(self, params, atm=None, terrain=None, objects=None, n_threads=0, rows=None):
+        """rows = (stride, phase): only rows y % stride == phase are computed (Fast / Rectilinear; see oracle.h)."""
         own = terrain is None
         if own:
             terrain = self.lib.oracle_terrain_new()
@@ -164,7 +167,13 @@ class Oracle:
         objs = objects or []
         arr = (_abi.Object * max(1, len(objs)))(*objs)
         res = _abi.Result()
-        rc = self.lib.oracle_generate(C.byref(params), C.byref(atm), terrain, arr, len(objs), n_threads, C.byref(res))
+        if rows is not None:
+            self.lib.oracle_set_row_filter(int(rows[0]), int(rows[1]))
+        try:
+            rc = self.lib.oracle_generate(C.byref(params), C.byref(atm), terrain, arr, len(objs), n_threads, C.byref(res))
+        finally:
+            if rows is not None:
+                self.lib.oracle_set_row_filter(1, 0)
         if own:
             self.lib.oracle_terrain_free(terrain)
         if rc != 0:

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_sizes_match_the_header(lib):
     for which, st in enumerate((_abi.Params, _abi.Atmosphere, _abi.Object, _abi.Result, _abi.DevicePlanes, _abi.EarthModel,
-                                _abi.Position, _abi.Frame)):
+                                _abi.Position, _abi.Frame, _abi.FrameStats, _abi.Timings, _abi.Coloring, _abi.DeviceHits)):
         assert lib.atmrt_abi_sizeof(which) == C.sizeof(st), st.__name__
 
 
@@ -43,7 +43,7 @@ def test_defaults_match_the_reference(lib):
     a = _abi.Atmosphere()
     lib.atmrt_atmosphere_us76(C.byref(a))
     assert a.n_functions == 7 and a.pressure == 101325.0 and a.temperature == 288.15 and a.functions[0].gradient == -0.0065
-    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 2
+    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 3
 
 
 def test_no_cpu_fallback(lib):

@@ -242,3 +242,23 @@ def test_last_hits_device_matches_host_result(gpu_ctx):
     g2 = generators.make_generator(generators.Params(cfg), generators.Terrain(gpu_ctx))
     g2.generate_device(_abi.DevicePlanes(**{k: v.data_ptr() for k, v in t.items()}))
     assert gpu_ctx.lib.atmrt_last_hits_device(gpu_ctx.handle, None, C.byref(n)) == _abi.ERR_STATE
+
+
+def test_failed_frame_invalidates_the_last_frame(gpu_ctx):
+    """After a frame that fails, atmrt_draw_image / atmrt_last_hits_device must refuse with ATMRT_ERR_STATE instead of reading
+    the (reused or reallocated) buffers of the frame before it."""
+    from atm_raytracer_amd import generators
+    cfg, tiles = synth.scene("S2", 64, 32, generator="InterpolatingRectilinear", terrain_alpha=0.5)
+    run_gpu(gpu_ctx, cfg, tiles)  # a good frame with packed trace points
+    col = generators.into_coloring(gpu_ctx.lib, cfg.params, cfg.coloring)
+    rgb = np.zeros((32, 64, 3), dtype=np.uint8)
+    gpu_ctx.check(gpu_ctx.lib.atmrt_draw_image(gpu_ctx.handle, C.byref(col), rgb.ctypes.data))
+    bad, _ = synth.scene("S2", 64, 32, generator="InterpolatingRectilinear", fov=0.0)  # every ray the same: no lattice step
+    with pytest.raises(AtmrtError) as e:
+        run_gpu(gpu_ctx, bad, tiles)
+    assert e.value.status == _abi.ERR_INVALID_ARGUMENT
+    assert gpu_ctx.lib.atmrt_draw_image(gpu_ctx.handle, C.byref(col), rgb.ctypes.data) == _abi.ERR_STATE
+    n = C.c_uint64()
+    assert gpu_ctx.lib.atmrt_last_hits_device(gpu_ctx.handle, None, C.byref(n)) == _abi.ERR_STATE
+    run_gpu(gpu_ctx, cfg, tiles)  # and the context recovers
+    gpu_ctx.check(gpu_ctx.lib.atmrt_draw_image(gpu_ctx.handle, C.byref(col), rgb.ctypes.data))

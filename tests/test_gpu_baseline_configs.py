@@ -1,0 +1,140 @@
+"""The BASELINE.json workloads AS STATED, on the GPU, against the oracle (configs 3, 4, 5 and the benched level-2
+mosaic had only been run reduced or by bench.py).
+
+The oracle cannot compute a whole 8-33 Mpixel frame in test time, so — as test_full_size_column_samples_match_oracle does for
+the headline — it computes column shards (`col_begin/col_end`, the same mechanism a multi-GPU rank uses) of the SAME frame and
+the GPU's full frame must hold exactly those bits in those columns: azimuth, elevation angle, hit count and every field of
+every trace point.  For the 1000-object scene the reference's eager per-sample object filter (utils.rs:74-80) makes even two
+Rectilinear columns minutes of CPU time, so the oracle computes every 8th row of them (oracle_set_row_filter)."""
+import numpy as np
+import pytest
+
+from atm_raytracer_amd import synth
+from util import assert_bitexact, assert_columns_match, frame_stats, run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s3_tiles():
+    return synth.scene("S3")[1]
+
+
+@pytest.fixture(scope="module")
+def s4_tiles():
+    return synth.scene("S4")[1]
+
+
+@pytest.fixture(scope="module")
+def s3_tiles_level2():
+    return synth.scene("headline", level=2)[1]
+
+
+def _shard(name, generator, c0, w=2, **kw):
+    cfg = synth.scene(name, generator=generator, **kw)[0]
+    cfg.params.col_begin, cfg.params.col_end = c0, c0 + w
+    return cfg
+
+
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast"])
+def test_config3_4096x2048_step_50m(gpu_ctx, oracle_det, s3_tiles, generator):
+    """BASELINE config 3: 4096x2048, 3x3 tiles, step 50 m, 200 km (N_t = 4000 samples per ray)."""
+    cfg = synth.scene("S3", generator=generator)[0]
+    assert (cfg.params.width, cfg.params.height, cfg.params.simulation_step, cfg.params.frame.max_distance) == (4096, 2048, 50.0, 200_000.0)
+    full = run_gpu(gpu_ctx, cfg, s3_tiles)
+    assert full["hit_count"].shape == (2048, 4096) and full["n_hits"] > 1_000_000
+    n = 0
+    for c0 in (0, 2049, 4094):
+        n += assert_columns_match(full, run_oracle(oracle_det, _shard("S3", generator, c0), s3_tiles), c0)
+    assert n > 1000
+
+
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast"])
+def test_config4_8192x4096_5x5_tiles_and_one_of_eight_shards(gpu_ctx, oracle_det, s4_tiles, generator):
+    """BASELINE config 4: 8192x4096 over 5x5 tiles — the whole frame on one GPU, and the shard rank 3 of 8 would compute
+    (columns 3072..4095), both against the oracle's columns; the shard must also equal the full frame's columns."""
+    cfg = synth.scene("S4", generator=generator)[0]
+    assert (cfg.params.width, cfg.params.height, len(s4_tiles)) == (8192, 4096, 25)
+    c_lo, c_hi = 3 * 8192 // 8, 4 * 8192 // 8
+    wants = {c0: run_oracle(oracle_det, _shard("S4", generator, c0), s4_tiles) for c0 in (0, c_lo, c_hi - 2, 8190)}
+    shard = _shard("S4", generator, c_lo, c_hi - c_lo)
+    part = run_gpu(gpu_ctx, shard, s4_tiles)
+    assert part["hit_count"].shape == (4096, 1024)
+    n = assert_columns_match(part, wants[c_lo], c_lo, x0=c_lo) + assert_columns_match(part, wants[c_hi - 2], c_hi - 2, x0=c_lo)
+    full = run_gpu(gpu_ctx, cfg, s4_tiles)
+    assert full["hit_count"].shape == (4096, 8192)
+    for c0, want in wants.items():
+        n += assert_columns_match(full, want, c0)
+    assert n > 2000
+    for k in ("azimuth", "elevation_angle", "hit_count"):
+        assert np.array_equal(part[k], full[k][:, c_lo:c_hi]), k
+    sel = part["hit_count"] > 0
+    for k in ("lat", "distance", "elevation"):
+        a = part[k][part["hit_offset"][sel].astype(np.int64)]
+        b = full[k][full["hit_offset"][:, c_lo:c_hi][sel].astype(np.int64)]
+        assert np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast", "InterpolatingRectilinear"])
+def test_config5_headline_1000_objects_translucent_terrain(gpu_ctx, oracle_det, s3_tiles, generator):
+    """BASELINE config 5: the headline frame + 700 frusta / 300 textured billboards (seed 4321) + terrain_alpha 0.5.  The oracle
+    columns are chosen where the GPU's frame is busiest (most trace points in a pixel, most object points in a column)."""
+    cfg = synth.scene("headline", generator=generator, terrain_alpha=0.5)[0]
+    synth.add_objects(cfg)
+    assert len(cfg.objects) == 1000
+    full = run_gpu(gpu_ctx, cfg, s3_tiles)
+    stats = frame_stats(gpu_ctx)
+    hc = full["hit_count"]
+    assert hc.shape == (2048, 4096)
+    assert (hc > 4).sum() > 1000, "pixels beyond the 4 slots of the counting pass"
+    per_px_obj = np.zeros(hc.size, dtype=np.int64)
+    pix_of_hit = np.repeat(np.arange(hc.size), hc.ravel())
+    np.add.at(per_px_obj, pix_of_hit, (full["color_tag"] == 1).astype(np.int64))
+    obj_cols = per_px_obj.reshape(hc.shape).sum(axis=0)
+    assert obj_cols.sum() > 10_000, "the scene must produce object trace points"
+    busiest = int(np.argmax(hc.max(axis=0)))
+    most_objects = int(np.argmax(obj_cols))
+    print(f"config 5 {generator}: {full['n_hits']} trace points, max {hc.max()} per pixel, {int((hc > 4).sum())} pixels over 4, "
+          f"{int(obj_cols.sum())} object points, stats {stats}")
+    if generator == "Rectilinear":
+        assert stats["retraced_pixels"] == int((hc > 4).sum())
+    rows = (8, 3) if generator == "Rectilinear" else None
+    n = 0
+    for c0 in sorted({min(busiest, 4094), min(most_objects, 4094), 1777}):
+        shard = synth.scene("headline", generator=generator, terrain_alpha=0.5)[0]
+        synth.add_objects(shard)
+        shard.params.col_begin, shard.params.col_end = c0, c0 + 2
+        n += assert_columns_match(full, run_oracle(oracle_det, shard, s3_tiles, rows=rows), c0, rows=rows)
+    assert n > 200
+
+
+def test_config5_candidate_lists_overflow(gpu_ctx, oracle_det, s3_tiles):
+    """Config 5's object population crowded into a 4-degree sector: more candidate objects per ray than the 24 of the Rectilinear
+    tracer's list and per column than the 64 of the Fast tracer's — the affected rays / columns test every object.  Same
+    full-size frame, checked against oracle columns through the crowded sector."""
+    for generator, key in (("Rectilinear", "unlisted_rays"), ("Fast", "unlisted_columns")):
+        kw = dict(generator=generator, terrain_alpha=0.5)
+        cfg = synth.scene("headline", **kw)[0]
+        synth.add_objects(cfg, spread_deg=2.0)
+        full = run_gpu(gpu_ctx, cfg, s3_tiles)
+        stats = frame_stats(gpu_ctx)
+        print(f"crowded config 5 {generator}: {stats}, max {full['hit_count'].max()} trace points per pixel")
+        assert stats[key] > 0, stats
+        rows = (16, 5) if generator == "Rectilinear" else None
+        for c0 in (2040, 2090):
+            shard = synth.scene("headline", **kw)[0]
+            synth.add_objects(shard, spread_deg=2.0)
+            shard.params.col_begin, shard.params.col_end = c0, c0 + 2
+            assert_columns_match(full, run_oracle(oracle_det, shard, s3_tiles, rows=rows), c0, rows=rows)
+
+
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast"])
+def test_headline_on_the_benched_level2_mosaic(gpu_ctx, oracle_det, s3_tiles_level2, generator):
+    """What bench.py runs: the headline frame over 9 level-2 tiles (3601 x 3601 posts each, 233 MB mosaic)."""
+    assert all(t.shape == (3601, 3601) for t in s3_tiles_level2.values())
+    cfg = synth.scene("headline", generator=generator)[0]
+    full = run_gpu(gpu_ctx, cfg, s3_tiles_level2)
+    n = 0
+    for c0 in (0, 1777, 4094):
+        n += assert_columns_match(full, run_oracle(oracle_det, _shard("headline", generator, c0), s3_tiles_level2), c0)
+    assert n > 1000

@@ -14,10 +14,19 @@ def run_gpu(ctx, cfg, tiles):
     return gen.generate()
 
 
-def run_oracle(oracle, cfg, tiles, n_threads=0):
+def frame_stats(ctx):
+    """atmrt_last_stats of the context's last frame."""
+    import ctypes as C
+    from atm_raytracer_amd import _abi
+    t = _abi.FrameStats()
+    ctx.check(ctx.lib.atmrt_last_stats(ctx.handle, C.byref(t)))
+    return {k: getattr(t, k) for k, _ in _abi.FrameStats._fields_}
+
+
+def run_oracle(oracle, cfg, tiles, n_threads=0, rows=None):
     t = oracle.terrain_new(tiles)
     try:
-        return oracle.generate(cfg.params, cfg.atmosphere, t, cfg.objects, n_threads)
+        return oracle.generate(cfg.params, cfg.atmosphere, t, cfg.objects, n_threads, rows)
     finally:
         oracle.terrain_free(t)
 
@@ -48,3 +57,25 @@ def assert_close(got, want, rtol):
     for k in ("lat", "lon", "distance", "elevation", "path_length"):
         np.testing.assert_allclose(got[k], want[k], rtol=rtol, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(got["normal"], want["normal"], rtol=rtol, atol=1e-7)
+
+
+def assert_columns_match(full, want, c0, rows=None, x0=0):
+    """`want` is the oracle's frame of the column shard [c0, c0 + w) of the frame `full` (the GPU's; its own column 0 is
+    frame column x0): every pixel plane and every trace point of those columns must be identical to the last bit, any
+    number of trace points per pixel.  rows = (stride, phase) restricts the comparison to the rows the oracle computed."""
+    H, w = want["hit_count"].shape
+    ys = np.arange(H) if rows is None else np.arange(rows[1], H, rows[0])
+    cols = slice(c0 - x0, c0 - x0 + w)
+    for k in ("azimuth", "elevation_angle", "hit_count"):
+        g, o = bits(full[k][ys, cols]), bits(want[k][ys])
+        assert np.array_equal(g, o), (k, c0, int((g != o).sum()))
+    cnt = want["hit_count"][ys].astype(np.int64).ravel()
+    goff = np.repeat(full["hit_offset"][ys, cols].astype(np.int64).ravel(), cnt)
+    woff = np.repeat(want["hit_offset"][ys].astype(np.int64).ravel(), cnt)
+    within = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    gi, wi = goff + within, woff + within
+    for k in FIELDS_HIT:
+        g, o = bits(full[k][gi]), bits(want[k][wi])
+        bad = np.flatnonzero((g != o).reshape(len(gi), -1).any(axis=1)) if len(gi) else np.zeros(0, int)
+        assert bad.size == 0, f"{k}: {bad.size} of {len(gi)} trace points differ in columns {c0}..{c0 + w - 1}"
+    return int(cnt.sum())

@@ -1,6 +1,6 @@
 """Command line mirroring the reference's subcommands (src/main.rs:17-39) over the C ABI:
 
-    python -m atm_raytracer_amd gen -c CONFIG.yaml [--output OUT.png] [--metadata OUT.npz]
+    python -m atm_raytracer_amd gen -c CONFIG.yaml [--output OUT.png] [--metadata OUT.npz|OUT.dat]
     python -m atm_raytracer_amd output-atm CONFIG.yaml [-a MIN] [-b MAX] [-s STEP] [-c]
     python -m atm_raytracer_amd output-ray-paths CONFIG.yaml [-h H] [-a MIN] [-b MAX] [-s DEG] [-r STEP] [-c CUTOFF] [-o OUTSTEP]
     python -m atm_raytracer_amd output-elev-profile CONFIG.yaml [-a AZIM] [-s STEP] [-c CUTOFF]
@@ -49,9 +49,14 @@ def cmd_gen(a):
     rgb = generators.draw_image(ctx, col, res["width"], res["height"])
     from PIL import Image
     Image.fromarray(rgb, "RGB").save(a.output)
-    if a.metadata:
+    meta_path = a.metadata or cfg.output["file_metadata"]  # `if let Some(ref filename) = params.output.file_metadata`, generator/mod.rs:88-94
+    if meta_path:
         stamp("Outputting metadata...")
-        np.savez_compressed(a.metadata, **{k: v for k, v in res.items() if isinstance(v, np.ndarray)})
+        if meta_path.endswith(".npz"):  # this package's own array dump
+            np.savez_compressed(meta_path, **{k: v for k, v in res.items() if isinstance(v, np.ndarray)})
+        else:  # the reference's format: gzip(bincode(AllData)), see metadata.py for the bytes that stay unpinned
+            from . import metadata
+            metadata.write_metadata(meta_path, cfg, res, col, metadata.object_elevations(cfg, terrain))
     stamp("Done.")
     return 0
 

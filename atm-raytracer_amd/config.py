@@ -152,6 +152,21 @@ def _object(node, load_texture):  # ConfObject, object/mod.rs:156-161
     return o, keep
 
 
+def _ticks(nodes, angle_key):
+    """Vec<Tick> / Vec<VerticalTick> (params.rs:306-367): externally tagged `Single{azimuth|elevation, size, labelled}` or
+    `Multiple{bias, step, size, labelled}`; every field is required (no serde default).  Kept for the metadata file only."""
+    out = []
+    for node in nodes or []:
+        (k, v), = node.items()
+        if k == "Single":
+            out.append(("Single", float(v[angle_key]), int(v["size"]), bool(v["labelled"])))
+        elif k == "Multiple":
+            out.append(("Multiple", float(v["bias"]), float(v["step"]), int(v["size"]), bool(v["labelled"])))
+        else:
+            raise ConfigError(f"unknown tick {k!r}")
+    return out
+
+
 def _load_texture(path):
     import numpy as np
     from PIL import Image
@@ -195,6 +210,10 @@ class Config:
         self.objects = []
         self._keepalive = []
         self.terrain_folder = "./terrain"  # default_terrain_folder, params.rs:72-74
+        self.texture_paths = []  # per object: ConfShape::Billboard.texture_path or None
+        # Output (params.rs:394-445): renderer-only fields, carried into the metadata file
+        self.output = {"file": "./output.png", "file_metadata": None, "ticks": [], "vertical_ticks": [], "show_eye_level": False,
+                       "show_flat_horizon": False}
         p = self.params
         p.position = _position(None)
         p.frame.direction, p.frame.tilt, p.frame.fov, p.frame.max_distance = 0.0, 0.0, 30.0, 150_000.0
@@ -215,6 +234,8 @@ class Config:
             o, keep = _object(node, load_texture)
             c.objects.append(o)
             c._keepalive.append(keep)
+            (shape_kind, shape), = node["shape"].items()
+            c.texture_paths.append(str(shape["texture_path"]) if shape_kind == "Billboard" else None)
         view = d.get("view") or {}
         c.coloring = _coloring(view)
         p.position = _position(view.get("position"))
@@ -233,6 +254,10 @@ class Config:
         if not (0 <= w <= 65535 and 0 <= h <= 65535):
             raise ConfigError("width/height must fit u16")  # params.rs:398-402
         p.width, p.height = w, h
+        c.output = {"file": str(out.get("file", "./output.png")), "file_metadata": out.get("file_metadata"),
+                    "ticks": _ticks(out.get("ticks"), "azimuth"), "vertical_ticks": _ticks(out.get("vertical_ticks"), "elevation"),
+                    "show_eye_level": bool(out.get("show_eye_level", False)),
+                    "show_flat_horizon": bool(out.get("show_flat_horizon", False))}
         gen = out.get("generator", "Fast")
         if gen not in _abi.GENERATORS:
             raise ConfigError(f"unknown generator {gen!r}")

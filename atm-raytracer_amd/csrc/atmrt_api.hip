@@ -15,6 +15,7 @@
 #include <utility>
 #include <vector>
 
+#include "atmrt_hostmem.h"
 #include "atmrt_kernels.h"
 #include "atmrt_render.h"
 #include "atmrt_tiff.h"
@@ -66,6 +67,7 @@ struct atmrt_ctx {
   int scan_segments = 0;                       // segments of the last pipelined frame (0: ev[4]..ev[5] time the scan)
   atmrt_timings_t timings{};
   atmrt_frame_stats_t stats{};
+  bool inject_failure = false; // atmrt_debug_fail_next_frame
   std::string error;
 
   // terrain (Terrain, terrain/mod.rs:55-57): tiles keyed by integer degrees
@@ -948,6 +950,11 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   if (f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR) rc = run_interpolating(c, f, ws, dense, &packed, n_hits_out);
   else rc = run_core(c, f, ws, dense, want_packed, &packed, n_hits_out);
   if (rc) return rc;
+  if (c->inject_failure) { // test hook: the frame's kernels have run and its buffers have been rewritten; now fail
+    c->inject_failure = false;
+    (void)hipStreamSynchronize(s);
+    return c->fail(ATMRT_ERR_HIP, "failure injected by atmrt_debug_fail_next_frame");
+  }
   uint64_t counters[N_COUNTERS] = {};
   HIP_TRY(c, hipEventRecord(c->ev_t1, s));
   HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
@@ -1065,6 +1072,38 @@ struct HostBlocks {
 HostBlocks g_host_blocks;
 } // namespace
 
+extern "C" int atmrt_internal_result_alloc(atmrt_result_t* out, uint32_t width, uint32_t height, uint64_t n_hits) {
+  memset(out, 0, sizeof *out);
+  const size_t npx = (size_t)width * height;
+  const size_t nh = n_hits ? n_hits : 1, np1 = npx ? npx : 1;
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t total = 3 * pad(np1 * 8) + pad(np1 * 4) + 5 * pad(nh * 8) + pad(nh * 24) + pad(nh * 4) + pad(nh * 32);
+  char* base = static_cast<char*>(g_host_blocks.take(total));
+  if (!base) return -1;
+  auto carve = [&](size_t bytes) {
+    void* r = base;
+    base += pad(bytes);
+    return r;
+  };
+  out->width = width;
+  out->height = height;
+  out->n_pixels = npx;
+  out->n_hits = n_hits;
+  out->azimuth = (double*)carve(np1 * 8); // first: atmrt_result_free returns the block by this pointer
+  out->elevation_angle = (double*)carve(np1 * 8);
+  out->hit_offset = (uint64_t*)carve(np1 * 8);
+  out->hit_count = (uint32_t*)carve(np1 * 4);
+  out->lat = (double*)carve(nh * 8);
+  out->lon = (double*)carve(nh * 8);
+  out->distance = (double*)carve(nh * 8);
+  out->elevation = (double*)carve(nh * 8);
+  out->path_length = (double*)carve(nh * 8);
+  out->normal = (double*)carve(nh * 24);
+  out->rgba = (double*)carve(nh * 32);
+  out->color_tag = (uint32_t*)carve(nh * 4);
+  return 0;
+}
+
 extern "C" void atmrt_result_free(atmrt_result_t* r) {
   if (!r) return;
   if (r->azimuth) g_host_blocks.give(r->azimuth); // the first array is the base of the block
@@ -1087,35 +1126,10 @@ extern "C" int atmrt_generate(atmrt_ctx* c, atmrt_result_t* out) {
   double ms = 0;
   if ((rc = run_generator(c, f, ws, dense, true, &packed, &n_hits, &steps, &ms))) return rc;
 
-  out->width = (uint32_t)f.wl;
-  out->height = (uint32_t)f.h;
-  out->n_pixels = npx;
-  out->n_hits = n_hits;
+  if (atmrt_internal_result_alloc(out, (uint32_t)f.wl, (uint32_t)f.h, n_hits))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "out of host memory for %zu pixels / %llu hits", npx, (unsigned long long)n_hits);
   out->ray_steps = steps;
   out->device_ms = ms;
-  size_t nh = n_hits ? n_hits : 1;
-  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
-  const size_t total = 3 * pad(npx * 8) + pad(npx * 4) + 5 * pad(nh * 8) + pad(nh * 24) + pad(nh * 4) + pad(nh * 32);
-  char* base = static_cast<char*>(g_host_blocks.take(total));
-  if (!base)
-    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "out of host memory for %zu pixels / %llu hits", npx, (unsigned long long)n_hits);
-  auto carve = [&](size_t bytes) {
-    void* r = base;
-    base += pad(bytes);
-    return r;
-  };
-  out->azimuth = (double*)carve(npx * 8); // first: atmrt_result_free returns the block by this pointer
-  out->elevation_angle = (double*)carve(npx * 8);
-  out->hit_offset = (uint64_t*)carve(npx * 8);
-  out->hit_count = (uint32_t*)carve(npx * 4);
-  out->lat = (double*)carve(nh * 8);
-  out->lon = (double*)carve(nh * 8);
-  out->distance = (double*)carve(nh * 8);
-  out->elevation = (double*)carve(nh * 8);
-  out->path_length = (double*)carve(nh * 8);
-  out->normal = (double*)carve(nh * 24);
-  out->rgba = (double*)carve(nh * 32);
-  out->color_tag = (uint32_t*)carve(nh * 4);
   hipStream_t s = c->stream;
   auto d2h = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s); };
   hipError_t e = d2h(out->azimuth, dense.azimuth, npx * 8);
@@ -1200,6 +1214,12 @@ extern "C" int atmrt_last_hits_device(atmrt_ctx* c, const atmrt_device_hits_t* d
 extern "C" int atmrt_last_timings(atmrt_ctx* c, atmrt_timings_t* out) {
   if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
   *out = c->timings;
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_debug_fail_next_frame(atmrt_ctx* c) {
+  if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  c->inject_failure = true;
   return ATMRT_OK;
 }
 

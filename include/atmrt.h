@@ -228,7 +228,9 @@ int atmrt_objects_set(atmrt_ctx* ctx, const atmrt_object_t* objects, size_t n);
  * device-to-host copy runs at PCIe speed; release it (as a whole) with atmrt_result_free, which keeps the block for the next frame. */
 int atmrt_generate(atmrt_ctx* ctx, atmrt_result_t* out);
 void atmrt_result_free(atmrt_result_t* r);
-/* Same computation, results left in HBM in caller-provided planes; ray_steps/device_ms optional. */
+/* Same computation, results left in HBM in caller-provided planes; ray_steps/device_ms optional.  The planes must stay
+ * allocated until the next generate call on ctx or until the last atmrt_draw_image* / atmrt_last_hits_device call for this
+ * frame, whichever comes first: those read the first-hit planes of an opaque frame in place. */
 int atmrt_generate_device(atmrt_ctx* ctx, const atmrt_device_planes_t* planes, uint64_t* ray_steps,
                           double* device_ms);
 
@@ -276,6 +278,10 @@ typedef struct atmrt_frame_stats {
   uint64_t big_blend_pixels;  /* InterpolatingRectilinear: pixels whose four lattice corners hold more than 64 trace points */
 } atmrt_frame_stats_t;
 int atmrt_last_stats(atmrt_ctx* ctx, atmrt_frame_stats_t* out);
+/* Fault injection for tests of the error paths: the next atmrt_generate / atmrt_generate_device on ctx runs its kernels and then
+ * fails with ATMRT_ERR_HIP (once).  After ANY failed frame atmrt_draw_image* and atmrt_last_hits_device return ATMRT_ERR_STATE
+ * until a frame succeeds: the failed frame has already reused the buffers of the one before it. */
+int atmrt_debug_fail_next_frame(atmrt_ctx* ctx);
 
 /* ---- renderer compositing + colouring on the device (src/renderer/mod.rs:367-414, src/coloring) -- */
 typedef enum atmrt_coloring_kind { ATMRT_COLORING_SIMPLE = 0, ATMRT_COLORING_SHADING = 1 } atmrt_coloring_kind;
@@ -313,6 +319,18 @@ int atmrt_atmosphere_sample(atmrt_ctx* ctx, size_t n, const double* altitude, do
 /* DirectionalCalc::coords_at_dist (directional_calc.rs:5-7) for the context's earth model. */
 int atmrt_coords_at_dist(atmrt_ctx* ctx, double lat0, double lon0, double dir_deg, size_t n, const double* dist,
                          double* lat, double* lon);
+
+/* ---- the metadata file (src/generator/mod.rs:20-45, read back by src/viewer/mod.rs:17-29) -------- */
+/* bincode-1 encoding of `result: Vec<Vec<ResultPixel>>` exactly as serde derives it (generators/mod.rs:13-49): u64 lengths,
+ * u32 enum tags, f64 little-endian; layout in csrc/atmrt_metadata.hip.  vector3_len_prefix != 0 writes nalgebra's Vector3 as a
+ * sequence (u64 3 + 3 f64, what nalgebra 0.32's ArrayStorage serializer is believed to emit; crate absent, UNPINNED), 0 as
+ * three bare f64.  Host-only functions (no device work, callable without a GPU).  dst == NULL queries *n_bytes. */
+int atmrt_result_encode_bincode(const atmrt_result_t* r, int32_t vector3_len_prefix, uint8_t* dst, size_t capacity,
+                                size_t* n_bytes);
+/* The inverse: `out` is library-allocated (release with atmrt_result_free); *consumed = bytes read from src.  Rows of unequal
+ * length, an unknown PixelColor tag or a truncated buffer give ATMRT_ERR_FORMAT. */
+int atmrt_result_decode_bincode(const uint8_t* src, size_t n_bytes, int32_t vector3_len_prefix, atmrt_result_t* out,
+                                size_t* consumed);
 
 /* The deterministic elementary functions of the device path (csrc/detmath.h), element-wise on host arrays: the same
  * instruction sequences the marching kernels execute.  The bit-exactness claim of this library rests on them returning, on

@@ -59,3 +59,31 @@ def test_cli_gen_and_diagnostics(workdir, oracle_det):
     prof = [tuple(float(v) for v in l.split("\t")) for l in r.stdout.strip().splitlines()]
     assert [p[0] for p in prof] == [0.0, 500.0, 1000.0, 1500.0, 2000.0, 2500.0, 3000.0]
     assert all(0.0 <= p[1] <= 4000.0 for p in prof)
+
+
+@pytest.mark.gpu
+def test_cli_gen_writes_the_metadata_file(workdir):
+    """`output.file_metadata` (generator/mod.rs:88-94): gzip(bincode(AllData)) next to the image; read back like `view` does
+    (viewer/mod.rs:17-29) it must hold the frame the array dump holds, and the Params of the YAML."""
+    from atm_raytracer_amd import metadata
+    doc = yaml.safe_load((workdir / "cfg.yaml").read_text())
+    doc["output"]["file_metadata"] = "meta.dat"
+    doc["scene"]["terrain_alpha"] = 0.5
+    doc["scene"]["objects"] = [{"position": {"latitude": 46.52, "longitude": 8.5, "altitude": {"Relative": 0.0}},
+                                "shape": {"Cylinder": {"radius": 80.0, "height": 600.0}}, "color": {"r": 1.0, "g": 0.0, "b": 0.0, "a": 0.5}}]
+    (workdir / "cfg2.yaml").write_text(yaml.safe_dump(doc))
+    r = run_cli(["gen", "-c", "cfg2.yaml", "--output", "out2.png"], str(workdir))
+    assert r.returncode == 0 and "Outputting metadata..." in r.stdout, r.stderr
+    meta = metadata.read_metadata(str(workdir / "meta.dat"))
+    r = run_cli(["gen", "-c", "cfg2.yaml", "--output", "out3.png", "--metadata", "out3.npz"], str(workdir))
+    assert r.returncode == 0, r.stderr
+    dump = np.load(workdir / "out3.npz")
+    res = meta["result"]
+    assert res["hit_count"].shape == (32, 64) and res["hit_count"].max() > 1 and (res["color_tag"] == 1).any()
+    for k in ("azimuth", "elevation_angle", "hit_count", "lat", "lon", "distance", "elevation", "path_length", "normal", "color_tag"):
+        assert np.array_equal(res[k], dump[k]), k
+    p = meta["params"]
+    assert p["scene"]["terrain_alpha"] == 0.5 and p["view"]["fog_distance"] == 80000.0 and p["output"]["file_metadata"] == "meta.dat"
+    obj = p["scene"]["objects"][0]
+    assert obj["shape"] == {"Frustum": {"r1": 80.0, "r2": 80.0, "height": 600.0}} and obj["position"]["elev"] > 0.0  # Altitude::abs on the terrain
+    assert p["model"] == {"Spherical": {"radius": 6371000.0}} and p["simulation_step"] == 100.0

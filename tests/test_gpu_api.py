@@ -253,10 +253,10 @@ def test_failed_frame_invalidates_the_last_frame(gpu_ctx):
     col = generators.into_coloring(gpu_ctx.lib, cfg.params, cfg.coloring)
     rgb = np.zeros((32, 64, 3), dtype=np.uint8)
     gpu_ctx.check(gpu_ctx.lib.atmrt_draw_image(gpu_ctx.handle, C.byref(col), rgb.ctypes.data))
-    bad, _ = synth.scene("S2", 64, 32, generator="InterpolatingRectilinear", fov=0.0)  # every ray the same: no lattice step
+    gpu_ctx.check(gpu_ctx.lib.atmrt_debug_fail_next_frame(gpu_ctx.handle))
     with pytest.raises(AtmrtError) as e:
-        run_gpu(gpu_ctx, bad, tiles)
-    assert e.value.status == _abi.ERR_INVALID_ARGUMENT
+        run_gpu(gpu_ctx, cfg, tiles)
+    assert e.value.status == _abi.ERR_HIP and "injected" in e.value.message
     assert gpu_ctx.lib.atmrt_draw_image(gpu_ctx.handle, C.byref(col), rgb.ctypes.data) == _abi.ERR_STATE
     n = C.c_uint64()
     assert gpu_ctx.lib.atmrt_last_hits_device(gpu_ctx.handle, None, C.byref(n)) == _abi.ERR_STATE

@@ -103,7 +103,8 @@ struct atmrt_ctx {
   DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
-      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev;
+      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev, d_step_prop,
+      d_blend_arena;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -697,6 +698,7 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->counters = c->d_counters.as<uint64_t>();
   ws->list_step = nullptr;
   ws->list_pixel = nullptr;
+  ws->step_prop = nullptr;
   return ATMRT_OK;
 }
 
@@ -783,11 +785,15 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
   HIP_TRY(c, hipEventRecord(ev[7], s));
   PackedHits packed{};
   if (want_packed || !f.opaque) {
-    uint64_t counters[4] = {0, 0, 0, 0};
+    uint64_t counters[N_COUNTERS] = {};
     launch_scan_counts(f, ws, dense.hit_count, s);
     HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     uint64_t n_hits = counters[1];
+    if (counters[6]) { // some step produced more trace points than StepHits keeps: the fill pass sorts those in place by `prop`
+      HIP_TRY(c, c->d_step_prop.reserve((n_hits + 1) * sizeof(double)));
+      ws.step_prop = c->d_step_prop.as<double>();
+    }
     HIP_TRY(c, c->d_packed.reserve(packed_bytes(n_hits)));
     packed = carve_packed(c->d_packed.ptr, n_hits);
     if (f.opaque) {
@@ -918,13 +924,34 @@ static int run_interpolating(atmrt_ctx* c, const Frame& f, Workspace& ws, const 
   fb.ei0 = fl.ei0;
   launch_interp_blend(fb, ws, ib, lr, false, dense, none, s);
   launch_scan_counts(f, ws, dense.hit_count, s);
-  uint64_t counters[4] = {0, 0, 0, 0};
+  uint64_t counters[N_COUNTERS] = {};
   HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  BlendArena arena{};
+  if (counters[7]) { // pixels whose four corners hold more points than the in-register member list: blended over an HBM arena
+    const size_t n = (size_t)counters[8];
+    HIP_TRY(c, c->d_blend_arena.reserve(n * (8 + 8 + 4 + 1 + 1) + 4 * 256));
+    char* a = c->d_blend_arena.as<char>();
+    auto take = [&](size_t b) {
+      void* r = a;
+      a += (b + 255) / 256 * 256;
+      return r;
+    };
+    arena.k = (uint64_t*)take(n * 8);
+    arena.dist = (double*)take(n * 8);
+    arena.group = (uint32_t*)take(n * 4);
+    arena.corner = (uint8_t*)take(n);
+    arena.tag = (uint8_t*)take(n);
+    launch_interp_blend_big(fb, ws, ib, lr, false, dense, none, arena, s);
+    launch_scan_counts(f, ws, dense.hit_count, s); // again, now that every pixel has its count
+    HIP_TRY(c, hipMemcpyAsync(counters, ws.counters, sizeof counters, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+  }
   uint64_t n_hits = counters[1];
   HIP_TRY(c, c->d_packed.reserve(packed_bytes(n_hits)));
   PackedHits packed = carve_packed(c->d_packed.ptr, n_hits);
   launch_interp_blend(fb, ws, ib, lr, true, dense, packed, s);
+  if (arena.k) launch_interp_blend_big(fb, ws, ib, lr, true, dense, packed, arena, s);
   launch_interp_finish(f, ws, ib, lr, dense, packed, s);
   if (packed_out) *packed_out = packed;
   if (n_hits_out) *n_hits_out = n_hits;
@@ -993,10 +1020,6 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     c->timings = t;
   }
   (void)fast;
-  if (counters[2])
-    return c->fail(ATMRT_ERR_UNSUPPORTED, "trace-point capacity exceeded (flags %llu): more than %d trace points in one step "
-                   "or more than %d trace points in four lattice corners",
-                   (unsigned long long)counters[2], 12, 64);
   c->stats.unlisted_rays = counters[4];
   c->stats.unlisted_columns = counters[5];
   c->stats.big_steps = counters[6];

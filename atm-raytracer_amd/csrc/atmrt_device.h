@@ -160,20 +160,19 @@ static __device__ __forceinline__ Earth earth_for(const Frame& f) {
 // close to either sample, stable-sorted by prop; stop after the step if anything opaque was hit.
 // Two passes (count -> exclusive scan -> fill) because the trace-point lists have variable length.
 // ---------------------------------------------------------------------------------------------
-constexpr int STEP_CANDIDATES = 12; // trace points one step may produce here (terrain + 4 per object); more sets the error flag
-
+constexpr int STEP_CANDIDATES = 12; // trace points of one step kept in registers (terrain + up to 4 per object); a step with more
+                                    // is counted exactly and written through the big-step route below (HBM, fill pass)
 
 struct StepHits {
-  int n;
+  int n;       // trace points pushed in this step; only the first STEP_CANDIDATES of them are kept below
   bool finish;
   int kind[STEP_CANDIDATES]; // -1 terrain, else object index
   Collision col[STEP_CANDIDATES];
 };
 
-static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int kind, const Collision* c,
-                                                 unsigned long long* counters) {
-  if (sh.n >= STEP_CANDIDATES) {
-    atomicOr(&counters[2], 1ull);
+static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int kind, const Collision* c) {
+  if (sh.n >= STEP_CANDIDATES) { // counted, not kept: the reference's step_result has no bound (utils.rs:213-282)
+    sh.n++;
     return;
   }
   int j = sh.n; // step_result.sort_by(prop) is stable: insert behind every element with prop <= new prop
@@ -195,17 +194,94 @@ static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int 
 static __device__ __forceinline__ bool object_out_of_band(const ObjectDev& o, double re0, double re1) {
   return (re0 < o.vlo && re1 < o.vlo) || (re0 > o.vhi && re1 > o.vhi); // false for NaN: the geometry then decides
 }
-static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2,
-                                                   unsigned long long* counters) {
+static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2) {
   Collision col[4];
   int nc = object_collision(f.objects[idx], f.textures, pos1, pos2, col);
   for (int q = 0; q < nc; q++) {
     if (col[q].color[3] == 0.0) continue;
-    step_push(sh, col[q].prop, idx, &col[q], counters);
+    step_push(sh, col[q].prop, idx, &col[q]);
     if (col[q].color[3] == 1.0) {
       sh.finish = true;
       break;
     }
+  }
+}
+
+// ---- big steps: more trace points in one step than StepHits keeps ------------------------------------------------------------
+// Fill pass only (the counting pass counts them exactly and raises counters[6]; such a pixel always exceeds its slots, so it is
+// traced again by the fill pass).  The step's points are produced a second time, written straight to their pixel's range of the
+// output list in production order with their `prop` beside them (Workspace::step_prop), and stable-sorted there by prop —
+// the same order as the reference's `step_result.sort_by(prop)` over its push order (utils.rs:279).
+struct StepGeom { // the two samples of the step: what an object point is interpolated from (utils.rs:261-272)
+  double lat0, lon0, re0, d0, pl0, lat1, lon1, re1, d1, pl1;
+};
+static __device__ __noinline__ void big_step_put(const PackedHits& packed, double* __restrict__ props, uint64_t k, double prop,
+                                                 const Collision* c, const StepGeom& g) {
+  props[k] = prop;
+  if (!c) {
+    packed.color_tag[k] = ATMRT_COLOR_TERRAIN; // completed by the *_finalize_list kernels
+    return;
+  }
+  packed.lat[k] = lerp_ts(g.lat0, g.lat1, prop);
+  packed.lon[k] = lerp_ts(g.lon0, g.lon1, prop);
+  packed.distance[k] = lerp_ts(g.d0, g.d1, prop);
+  packed.elevation[k] = lerp_ts(g.re0, g.re1, prop);
+  packed.path_length[k] = lerp_ts(g.pl0, g.pl1, prop);
+  packed.normal[3 * k] = c->normal.x;
+  packed.normal[3 * k + 1] = c->normal.y;
+  packed.normal[3 * k + 2] = c->normal.z;
+  packed.color_tag[k] = ATMRT_COLOR_RGBA;
+  for (int q = 0; q < 4; q++) packed.rgba[4 * k + q] = c->color[q];
+}
+static __device__ __forceinline__ void big_step_object(const PackedHits& packed, double* __restrict__ props, uint64_t& k,
+                                                       const Frame& f, int idx, Vec3 pos1, Vec3 pos2, const StepGeom& g) {
+  Collision col[4];
+  int nc = object_collision(f.objects[idx], f.textures, pos1, pos2, col);
+  for (int q = 0; q < nc; q++) {
+    if (col[q].color[3] == 0.0) continue;
+    big_step_put(packed, props, k++, col[q].prop, &col[q], g);
+    if (col[q].color[3] == 1.0) break;
+  }
+}
+// stable insertion sort of the n points at [k0, k0 + n) by prop (rare and short: O(n^2) moves in HBM)
+static __device__ __noinline__ void big_step_sort(const PackedHits& h, double* __restrict__ props, uint64_t k0, int n) {
+  for (int i = 1; i < n; i++) {
+    const uint64_t ki = k0 + i;
+    const double prop = props[ki];
+    if (!(props[ki - 1] > prop)) continue;
+    const double lat = h.lat[ki], lon = h.lon[ki], dist = h.distance[ki], elev = h.elevation[ki], pl = h.path_length[ki];
+    const double n0 = h.normal[3 * ki], n1 = h.normal[3 * ki + 1], n2 = h.normal[3 * ki + 2];
+    const double c0 = h.rgba[4 * ki], c1 = h.rgba[4 * ki + 1], c2 = h.rgba[4 * ki + 2], c3 = h.rgba[4 * ki + 3];
+    const uint32_t tag = h.color_tag[ki];
+    int j = i;
+    while (j > 0 && props[k0 + j - 1] > prop) {
+      const uint64_t d = k0 + j, s = d - 1;
+      props[d] = props[s];
+      h.lat[d] = h.lat[s];
+      h.lon[d] = h.lon[s];
+      h.distance[d] = h.distance[s];
+      h.elevation[d] = h.elevation[s];
+      h.path_length[d] = h.path_length[s];
+      for (int q = 0; q < 3; q++) h.normal[3 * d + q] = h.normal[3 * s + q];
+      for (int q = 0; q < 4; q++) h.rgba[4 * d + q] = h.rgba[4 * s + q];
+      h.color_tag[d] = h.color_tag[s];
+      j--;
+    }
+    const uint64_t d = k0 + j;
+    props[d] = prop;
+    h.lat[d] = lat;
+    h.lon[d] = lon;
+    h.distance[d] = dist;
+    h.elevation[d] = elev;
+    h.path_length[d] = pl;
+    h.normal[3 * d] = n0;
+    h.normal[3 * d + 1] = n1;
+    h.normal[3 * d + 2] = n2;
+    h.rgba[4 * d] = c0;
+    h.rgba[4 * d + 1] = c1;
+    h.rgba[4 * d + 2] = c2;
+    h.rgba[4 * d + 3] = c3;
+    h.color_tag[d] = tag;
   }
 }
 

@@ -79,8 +79,9 @@ struct PathSegState {
 // Device counters of a frame (Workspace::counters): [0] ray-steps, [1] total of the last scan (trace points), [2] error flags,
 // [3] scan total of the close lists / pixels that overflowed their slots / cursor of the overflow list, [4] rays whose candidate
 // list overflowed, [5] columns whose candidate list overflowed, [6] steps with more trace points than StepHits holds,
-// [7] InterpolatingRectilinear pixels with more corner points than the in-register member list
-constexpr int N_COUNTERS = 8;
+// [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
+// together (size of the member arena), [9] cursor of that arena
+constexpr int N_COUNTERS = 10;
 
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
@@ -120,6 +121,7 @@ struct Workspace {
   uint32_t* clist;        // object indices, ascending per sample
   int32_t* col_cand;      // [wl][64] objects that can be close to any sample of the column (ascending), and ...
   int32_t* col_ncand;     // ... their number; -1 = no list, test every object
+  double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
 };
 
@@ -145,6 +147,15 @@ struct LatticeResult { // the lattice frame's packed result
   const uint32_t* px_steps;
   int32_t nd, ne;
 };
+struct BlendArena { // member lists of the pixels k_interp_blend_big blends (more than 64 corner points)
+  uint64_t* k;
+  double* dist;
+  uint32_t* group;
+  uint8_t* corner;
+  uint8_t* tag;
+};
+void launch_interp_blend_big(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,
+                             const DensePlanes& dense, const PackedHits& packed, const BlendArena& arena, hipStream_t stream);
 void launch_fov_table(const Frame& f, const InterpBuffers& ib, hipStream_t stream);
 void launch_lattice_keys(const Frame& f, const InterpBuffers& ib, double min_elev_step, double min_dir_step, hipStream_t stream);
 void launch_interp_blend(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,

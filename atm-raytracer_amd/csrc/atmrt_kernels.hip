@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
                                                     const uint64_t* __restrict__ hit_offset, PackedHits packed,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     uint32_t* __restrict__ px_steps,
-                                                    unsigned long long* __restrict__ counters) {
+                                                    unsigned long long* __restrict__ counters, double* __restrict__ step_prop) {
   // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
   // (packed / list_step / list_pixel then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its
   // place in the pixel-ordered list — for the pixels that did not fit their slots (hit_count > RECT_SLOTS); the others were
@@ -539,35 +539,54 @@ __global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __res
         sh.n = 0;
         sh.finish = false;
         if (hit) {
-          step_push(sh, diff1 / (diff1 - diff2), -1, nullptr, counters);
+          step_push(sh, diff1 / (diff1 - diff2), -1, nullptr);
           if (terrain_opaque) sh.finish = true;
         }
         const double lat0 = kplat[s0], lon0 = kplon[s0], lat1 = kplat[s1], lon1 = kplon[s1];
         bool have_pos = false;
         Vec3 pos1 = v3(0.0, 0.0, 0.0), pos2 = pos1;
-        uint32_t ia = 0, ib = 0;
-        while (ia < c0 || ib < c1) {
-          uint32_t idx;
-          if (ib >= c1 || (ia < c0 && la[ia] <= lb[ib])) {
-            idx = la[ia];
-            if (ib < c1 && lb[ib] == idx) ib++;
-            ia++;
-          } else {
-            idx = lb[ib++];
+        // the union of the two ascending close lists, for the lanes whose segment enters the object's height band
+        auto for_each_object = [&](auto&& visit) {
+          uint32_t ia = 0, ib = 0;
+          while (ia < c0 || ib < c1) {
+            uint32_t idx;
+            if (ib >= c1 || (ia < c0 && la[ia] <= lb[ib])) {
+              idx = la[ia];
+              if (ib < c1 && lb[ib] == idx) ib++;
+              ia++;
+            } else {
+              idx = lb[ib++];
+            }
+            const double vlo = kobjects[idx].vlo, vhi = kobjects[idx].vhi;
+            if ((re0 < vlo && re1 < vlo) || (re0 > vhi && re1 > vhi)) continue; // most rows pass above or below the object
+            if (!have_pos) {
+              pos1 = as_cartesian(f.earth, lat0, lon0, re0);
+              pos2 = as_cartesian(f.earth, lat1, lon1, re1);
+              have_pos = true;
+            }
+            visit((int)idx);
           }
-          const double vlo = kobjects[idx].vlo, vhi = kobjects[idx].vhi;
-          if ((re0 < vlo && re1 < vlo) || (re0 > vhi && re1 > vhi)) continue; // most rows pass above or below the object
-          if (!have_pos) {
-            pos1 = as_cartesian(f.earth, lat0, lon0, re0);
-            pos2 = as_cartesian(f.earth, lat1, lon1, re1);
-            have_pos = true;
-          }
-          step_object(sh, f, (int)idx, pos1, pos2, counters);
+        };
+        for_each_object([&](int idx) { step_object(sh, f, idx, pos1, pos2); });
+        const double d0 = i == 1 ? 0.0 : f.xs[i - 1], pl0 = i == 1 ? 0.0 : plen_t[(size_t)(i - 1) * hh + y];
+        if (!FILL) {
+          k = (uint64_t)p * RECT_SLOTS + count;
+          if (sh.n > STEP_CANDIDATES) atomicAdd(&counters[6], 1ull); // the fill pass will need Workspace::step_prop
         }
-        if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;
-        if (sh.n && (FILL || count + (unsigned)sh.n <= (unsigned)RECT_SLOTS))
-          step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, i == 1 ? 0.0 : f.xs[i - 1],
-                    i == 1 ? 0.0 : plen_t[(size_t)(i - 1) * hh + y], lat1, lon1, re1, f.xs[i], plen_t[(size_t)i * hh + y]);
+        if (FILL && sh.n > STEP_CANDIDATES) { // big step: produce the points again, straight into the list, and sort them there
+          const StepGeom g{lat0, lon0, re0, d0, pl0, lat1, lon1, re1, f.xs[i], plen_t[(size_t)i * hh + y]};
+          const uint64_t k0 = k;
+          if (hit) big_step_put(packed, step_prop, k++, diff1 / (diff1 - diff2), nullptr, g);
+          for_each_object([&](int idx) { big_step_object(packed, step_prop, k, f, idx, pos1, pos2, g); });
+          big_step_sort(packed, step_prop, k0, sh.n);
+          for (uint64_t q = k0; q < k; q++) {
+            list_step[q] = (uint32_t)(i - 1);
+            list_pixel[q] = (uint32_t)p;
+          }
+        } else if (sh.n && (FILL || count + (unsigned)sh.n <= (unsigned)RECT_SLOTS)) {
+          step_emit(sh, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, re1, f.xs[i],
+                    plen_t[(size_t)i * hh + y]);
+        }
         count += (unsigned)sh.n;
         if (sh.finish) active = false;
       }
@@ -891,7 +910,8 @@ static __device__ FullTP tp_interpolate(const FullTP& a, const FullTP& b, double
   return r;
 }
 
-constexpr int INTERP_MEMBERS = 64; // trace points of the four corner pixels together; more sets the error flag
+constexpr int INTERP_MEMBERS = 64; // trace points of the four corner pixels together that the in-register member list holds;
+                                    // pixels with more are blended by k_interp_blend_big over a member arena in HBM
 
 // interpolate_trace_points :267-337 on the group's corner members (index -1 = None)
 static __device__ bool interp_group(const LatticeResult& lr, const uint64_t* member_k, const int e[4], double re, double rd,
@@ -941,6 +961,52 @@ static __device__ bool interp_group(const LatticeResult& lr, const uint64_t* mem
   }
 }
 
+// collect_trace_points :213-243 + match_sequence :245-265 + interpolate_trace_points per group for one pixel: the members
+// (trace points of the four corners, corner by corner) are grouped — a point joins the first group, in creation order, that
+// holds a point of its class within step_size of its distance — and every group is blended.  Returns the number of trace
+// points of the pixel; FILL writes them at k_out.  The member arrays hold at least the corners' total number of points.
+template <bool FILL, class GroupT>
+static __device__ __forceinline__ unsigned blend_members(const LatticeResult& lr, const size_t corner[4], double rem_elev,
+                                                         double rem_dir, double step_size, uint64_t* member_k, double* member_dist,
+                                                         uint8_t* member_corner, uint8_t* member_tag, GroupT* member_group,
+                                                         uint64_t k_out, const PackedHits& packed) {
+  int n_members = 0, n_groups = 0;
+  for (int c = 0; c < 4; c++) {
+    uint64_t k0 = lr.hit_offset[corner[c]];
+    uint32_t cnt = lr.hit_count[corner[c]];
+    for (uint32_t q = 0; q < cnt; q++) {
+      double dist = lr.hits.distance[k0 + q];
+      uint8_t tag = (uint8_t)lr.hits.color_tag[k0 + q];
+      int found = -1;
+      for (int g = 0; g < n_groups && found < 0; g++) // first group (creation order) with any close point of the same class
+        for (int m = 0; m < n_members; m++)
+          if ((int)member_group[m] == g && dm_fabs(dist - member_dist[m]) < step_size && tag == member_tag[m]) {
+            found = g;
+            break;
+          }
+      if (found < 0) found = n_groups++;
+      member_k[n_members] = k0 + q;
+      member_dist[n_members] = dist;
+      member_corner[n_members] = (uint8_t)c;
+      member_tag[n_members] = tag;
+      member_group[n_members] = (GroupT)found;
+      n_members++;
+    }
+  }
+  unsigned count = 0;
+  for (int g = 0; g < n_groups; g++) {
+    int e[4] = {-1, -1, -1, -1};
+    for (int m = 0; m < n_members; m++)
+      if ((int)member_group[m] == g) e[member_corner[m]] = m; // later entries overwrite, :247-263
+    FullTP tp;
+    if (interp_group(lr, member_k, e, rem_elev, rem_dir, tp)) {
+      if (FILL) store_tp(packed, k_out + count, tp);
+      count++;
+    }
+  }
+  return count;
+}
+
 // interpolate :395-418 with collect_trace_points :213-243 and match_sequence :245-265
 // CAP = 4: the pixels whose four lattice corners hold at most four trace points together (nearly all of them) — the member
 // arrays are four registers wide; CAP = INTERP_MEMBERS: the others.  Both instances run over the whole image, each pixel is
@@ -973,51 +1039,43 @@ __global__ __launch_bounds__(256) void k_interp_blend(Frame f, InterpBuffers ib,
     out.azimuth[p] = a0 * (1.0 - rem_elev) * (1.0 - rem_dir) + a1 * (1.0 - rem_elev) * rem_dir + a2 * rem_elev * (1.0 - rem_dir) +
                      a3 * rem_elev * rem_dir;
   }
-  if ((CAP == 4) != (total <= 4u)) return; // the other instance's pixel
+  if (!FILL && CAP == 4 && total > (uint32_t)INTERP_MEMBERS) { // k_interp_blend_big's pixel: size its member arena
+    atomicAdd(&counters[7], 1ull);
+    atomicAdd(&counters[8], (unsigned long long)total);
+  }
+  if (CAP == 4 ? total > 4u : (total <= 4u || total > (uint32_t)INTERP_MEMBERS)) return; // another instance's pixel
   uint64_t member_k[CAP];
   double member_dist[CAP];
   uint8_t member_corner[CAP], member_tag[CAP], member_group[CAP];
-  int n_members = 0, n_groups = 0;
-  for (int c = 0; c < 4; c++) {
-    uint64_t k0 = lr.hit_offset[corner[c]];
-    uint32_t cnt = lr.hit_count[corner[c]];
-    for (uint32_t q = 0; q < cnt; q++) {
-      if (n_members >= CAP) {
-        atomicOr(&counters[2], 4ull);
-        break;
-      }
-      double dist = lr.hits.distance[k0 + q];
-      uint8_t tag = (uint8_t)lr.hits.color_tag[k0 + q];
-      int found = -1;
-      for (int g = 0; g < n_groups && found < 0; g++) // first group (creation order) with any close point of the same class
-        for (int m = 0; m < n_members; m++)
-          if (member_group[m] == g && dm_fabs(dist - member_dist[m]) < step_size && tag == member_tag[m]) {
-            found = g;
-            break;
-          }
-      if (found < 0) found = n_groups++;
-      member_k[n_members] = k0 + q;
-      member_dist[n_members] = dist;
-      member_corner[n_members] = (uint8_t)c;
-      member_tag[n_members] = tag;
-      member_group[n_members] = (uint8_t)found;
-      n_members++;
-    }
-  }
-  uint64_t k = FILL ? hit_offset[p] : 0;
-  unsigned count = 0;
-  for (int g = 0; g < n_groups; g++) {
-    int e[4] = {-1, -1, -1, -1};
-    for (int m = 0; m < n_members; m++)
-      if (member_group[m] == g) e[member_corner[m]] = m; // later entries overwrite, :247-263
-    FullTP tp;
-    if (interp_group(lr, member_k, e, rem_elev, rem_dir, tp)) {
-      if (FILL) store_tp(packed, k + count, tp);
-      count++;
-    }
-  }
+  const unsigned count = blend_members<FILL>(lr, corner, rem_elev, rem_dir, step_size, member_k, member_dist, member_corner, member_tag,
+                                             member_group, FILL ? hit_offset[p] : 0, packed);
   if (!FILL) out.hit_count[p] = count;
 }
+
+// The pixels whose four lattice corners hold more than INTERP_MEMBERS trace points together (the reference's Vec has no bound,
+// interpolating_rectilinear.rs:213-243): same grouping and blend, member list in an HBM arena handed out by an atomic cursor
+// (each pixel's range is private, so the order in which pixels take their ranges does not matter).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_interp_blend_big(Frame f, InterpBuffers ib, LatticeResult lr, DensePlanes out,
+                                                          const uint64_t* __restrict__ hit_offset, PackedHits packed,
+                                                          BlendArena arena, unsigned long long* __restrict__ counters) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= f.wl) return;
+  const size_t p = (size_t)y * f.wl + x;
+  size_t corner[4];
+  uint32_t total = 0;
+  for (int s = 0; s < 4; s++) {
+    corner[s] = (size_t)(ib.key_e[p] + (s >> 1) - f.ei0) * lr.nd + (size_t)(ib.key_d[p] + (s & 1) - f.di0);
+    total += lr.hit_count[corner[s]];
+  }
+  if (total <= (uint32_t)INTERP_MEMBERS) return;
+  const unsigned long long base = atomicAdd(&counters[9], (unsigned long long)total);
+  const unsigned count = blend_members<FILL>(lr, corner, ib.rem_e[p], ib.rem_d[p], f.p.simulation_step, arena.k + base, arena.dist + base,
+                                             arena.corner + base, arena.tag + base, arena.group + base, FILL ? hit_offset[p] : 0, packed);
+  if (!FILL) out.hit_count[p] = count;
+}
+
 
 // ray-steps of the lattice pixels the image actually references (the reference memoises exactly those); grid-stride,
 // one atomic per block
@@ -1062,6 +1120,17 @@ void launch_interp_blend(const Frame& f, Workspace& ws, const InterpBuffers& ib,
     hipLaunchKernelGGL((k_interp_blend<false, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr,
                        packed, (unsigned long long*)ws.counters);
   }
+}
+void launch_interp_blend_big(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,
+                             const DensePlanes& dense, const PackedHits& packed, const BlendArena& arena, hipStream_t stream) {
+  dim3 grid(cdiv(f.wl, 256), f.h);
+  (void)hipMemsetAsync(ws.counters + 9, 0, sizeof(uint64_t), stream); // the arena cursor
+  if (fill)
+    hipLaunchKernelGGL((k_interp_blend_big<true>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed, arena,
+                       (unsigned long long*)ws.counters);
+  else
+    hipLaunchKernelGGL((k_interp_blend_big<false>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr, packed,
+                       arena, (unsigned long long*)ws.counters);
 }
 void launch_interp_finish(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr,
                           const DensePlanes& dense, const PackedHits& packed, hipStream_t stream) {
@@ -1354,7 +1423,7 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
                      ws.pelev_t, ws.plen_t);
   hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                      ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, out.hit_count, (const uint64_t*)nullptr,
-                     ws.slot_packed, ws.slot_step, ws.slot_pixel, ws.px_steps, (unsigned long long*)ws.counters);
+                     ws.slot_packed, ws.slot_step, ws.slot_pixel, ws.px_steps, (unsigned long long*)ws.counters, (double*)nullptr);
 }
 
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
@@ -1367,7 +1436,7 @@ void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
                      (const uint32_t*)dense.hit_count, ws.hit_offset, ws.slot_step, ws.slot_packed, ws.list_step, ws.list_pixel, packed);
   hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                      ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, dense.hit_count, ws.hit_offset, packed,
-                     ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters);
+                     ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters, ws.step_prop);
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                           stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,

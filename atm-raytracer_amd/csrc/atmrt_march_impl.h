@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
                                                     PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
                                                     uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
-                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list) {
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list,
+                                                    double* __restrict__ step_prop) {
   // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
   // (packed / rec / list_step then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its place in
   // the pixel-ordered list, for all pixels or for the listed ones (those that did not fit their slots).
@@ -262,31 +263,61 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         hits.n = 0;
         hits.finish = false;
         double diff1 = re0 - te0, diff2 = sh_ - te1;
-        if (diff1 * diff2 < 0.0) {
-          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr, counters);
+        const bool crossing = diff1 * diff2 < 0.0;
+        if (crossing) {
+          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr);
           if (terrain_opaque) hits.finish = true;
         }
+        // the objects this step tests, ascending: union of the close lists of its two samples (utils.rs:241-250)
+        unsigned m = 0u;
+        bool any_object = false;
         if (use_cand) {
-          unsigned m = m0 | m1;
+          m = m0 | m1;
           for (unsigned mm = m; mm; mm &= mm - 1) // drop the objects whose height band the segment does not enter
             if (object_out_of_band(f.objects[cand[__builtin_ctz(mm)]], re0, sh_)) m &= ~(mm & (0u - mm));
-          if (m) {
-            Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
-            while (m) {
-              const int q = __builtin_ctz(m);
-              m &= m - 1;
-              step_object(hits, f, cand[q], pos1, pos2, counters);
-            }
-          }
-        } else if (f.n_objects) {
-          const LatLonTrig t0 = latlon_trig(e, lat0, lon0), t1 = latlon_trig(e, lat1, lon1);
-          Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh_);
-          for (int j = 0; j < f.n_objects; j++)
-            if (!object_out_of_band(f.objects[j], re0, sh_) && (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)))
-              step_object(hits, f, j, pos1, pos2, counters);
+          any_object = m != 0u;
+        } else {
+          any_object = f.n_objects != 0;
         }
-        if (!FILL) k = (uint64_t)p * RECT_SLOTS + count;
-        if (hits.n && (FILL || count + (unsigned)hits.n <= (unsigned)RECT_SLOTS)) {
+        Vec3 pos1 = v3(0.0, 0.0, 0.0), pos2 = pos1;
+        LatLonTrig t0{}, t1{};
+        if (any_object) {
+          pos1 = as_cartesian(e, lat0, lon0, re0);
+          pos2 = as_cartesian(e, lat1, lon1, sh_);
+          if (!use_cand) {
+            t0 = latlon_trig(e, lat0, lon0);
+            t1 = latlon_trig(e, lat1, lon1);
+          }
+        }
+        auto for_each_object = [&](auto&& visit) {
+          if (use_cand) {
+            for (unsigned mm = m; mm; mm &= mm - 1) visit(cand[__builtin_ctz(mm)]);
+          } else {
+            for (int j = 0; j < f.n_objects; j++)
+              if (!object_out_of_band(f.objects[j], re0, sh_) && (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)))
+                visit(j);
+          }
+        };
+        if (any_object) for_each_object([&](int j) { step_object(hits, f, j, pos1, pos2); });
+        if (!FILL) {
+          k = (uint64_t)p * RECT_SLOTS + count;
+          if (hits.n > STEP_CANDIDATES) atomicAdd(&counters[6], 1ull); // the fill pass will need Workspace::step_prop
+        }
+        if (FILL && hits.n > STEP_CANDIDATES) { // big step: produce the points again, straight into the list, and sort them there
+          const StepGeom g{lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx, path_length};
+          const uint64_t k0 = k;
+          if (crossing) big_step_put(packed, step_prop, k++, diff1 / (diff1 - diff2), nullptr, g);
+          for_each_object([&](int j) { big_step_object(packed, step_prop, k, f, j, pos1, pos2, g); });
+          big_step_sort(packed, step_prop, k0, hits.n);
+          for (uint64_t q = k0; q < k; q++) {
+            list_step[q] = (uint32_t)(i - 1);
+            list_pixel[q] = (uint32_t)p;
+            rec.re0[q] = re0;
+            rec.pl0[q] = pl0;
+            rec.re1[q] = sh_;
+            rec.pl1[q] = path_length;
+          }
+        } else if (hits.n && (FILL || count + (unsigned)hits.n <= (unsigned)RECT_SLOTS)) {
           uint64_t k0 = k;
           step_emit(hits, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx,
                     path_length);
@@ -401,7 +432,7 @@ void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes&
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
                                                         (const uint64_t*)nullptr, ws.slot_packed, slots, ws.slot_step,
                                                         ws.slot_pixel, (unsigned long long*)ws.counters,
-                                                        (const uint32_t*)nullptr, 0u));
+                                                        (const uint32_t*)nullptr, 0u, (double*)nullptr));
 }
 
 // Trace points kept in the slot arena by the counting pass of k_rect_trace, moved to their places in the pixel-ordered list
@@ -458,7 +489,7 @@ void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, co
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC, CUBIC>), dim3(cdiv((size_t)ws.n_overflow, 256)), dim3(256), 0,
                                                           stream, f, dense, ws.hit_offset, packed, rec, ws.list_step, ws.list_pixel,
                                                           (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow,
-                                                          (uint32_t)ws.n_overflow));
+                                                          (uint32_t)ws.n_overflow, ws.step_prop));
   }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,

@@ -12,18 +12,22 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-PLANES = ("azimuth", "elevation_angle", "hit_count", "first_distance", "first_lat")
+PLANES = ("azimuth", "elevation_angle", "hit_count", "lat", "lon", "distance", "elevation", "path_length", "normal")
 
 
 def dense_planes(res):
-    """Dense first-hit planes like atmrt_generate_device writes them (NaN where the pixel has no trace point)."""
+    """Dense first-hit planes like atmrt_generate_device writes them (NaN where the pixel has no trace point; normal planar)."""
     out = {"azimuth": res["azimuth"], "elevation_angle": res["elevation_angle"], "hit_count": res["hit_count"].astype(np.int32)}
     first = res["hit_offset"].astype(np.int64)
     has = res["hit_count"] > 0
-    for name, src in (("first_distance", "distance"), ("first_lat", "lat")):
+    for name in ("lat", "lon", "distance", "elevation", "path_length"):
         plane = np.full(res["hit_count"].shape, np.nan)
-        plane[has] = res[src][first[has]]
+        plane[has] = res[name][first[has]]
         out[name] = plane
+    nrm = np.full((3,) + res["hit_count"].shape, np.nan)
+    for c in range(3):
+        nrm[c][has] = res["normal"][first[has], c]
+    out["normal"] = nrm
     return out
 
 
@@ -39,8 +43,18 @@ def worker(rank, world, port, width, height, generator, queue):
     c0, c1 = sharding.column_shard(width, rank, world)
     cfg.params.col_begin, cfg.params.col_end = c0, c1
     res = run_oracle(Oracle("det"), cfg, tiles, n_threads=2)
-    local = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in dense_planes(res).items()}
-    full = sharding.all_gather_planes(local, world, dist)
+    # what bench.py does per frame: the shard's planes live in one slab (here filled from the oracle's shard), ONE
+    # all_gather_into_tensor moves the slabs, and the same call leaves the [H][W] image — nothing happens after it
+    slab = sharding.PlaneSlab(height, c1 - c0, torch.device("cpu"))
+    for k, v in dense_planes(res).items():
+        slab.planes[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+    gather = sharding.ImageGather(slab, world)
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    full = gather(dist)
+    dist.all_gather_into_tensor = real
+    assert len(calls) == 1, "one collective per frame"
     steps = torch.tensor([res["ray_steps"]], dtype=torch.int64)
     dist.all_reduce(steps)
     if rank == 0:
@@ -69,7 +83,7 @@ def test_two_rank_column_shards_reassemble(generator, oracle_det):
     want = dense_planes(want_res)
     assert steps == want_res["ray_steps"]
     for k in PLANES:
-        assert got[k].shape == (height, width)
+        assert got[k].shape == ((3, height, width) if k == "normal" else (height, width))
         assert np.array_equal(got[k], want[k], equal_nan=True), k
 
 
@@ -88,11 +102,14 @@ def hits_worker(rank, world, port, width, height, queue):
     c0, c1 = sharding.column_shard(width, rank, world)
     cfg.params.col_begin, cfg.params.col_end = c0, c1
     res = run_oracle(Oracle("det"), cfg, tiles, n_threads=2)
-    hc = torch.from_numpy(np.ascontiguousarray(res["hit_count"].astype(np.int32)))
+    slab = sharding.PlaneSlab(height, c1 - c0, torch.device("cpu"))
+    for k, v in dense_planes(res).items():
+        slab.planes[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+    image = sharding.ImageGather(slab, world)(dist)
     hits = {k: torch.from_numpy(np.ascontiguousarray(res[k].astype(np.int32) if k == "color_tag" else res[k])) for k in HIT_FIELDS}
-    counts, offsets, full = sharding.all_gather_hits(hc, hits, world, dist)
+    offsets, full = sharding.gather_hits(image["hit_count"], hits, world, dist)
     if rank == 0:
-        queue.put((counts.numpy(), offsets.numpy(), {k: v.numpy() for k, v in full.items()}))
+        queue.put((image["hit_count"].numpy(), offsets.numpy(), {k: v.numpy() for k, v in full.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -130,3 +147,18 @@ def test_assemble_layout():
     planar = torch.stack([shards, shards + 100.0], dim=1)  # [G, 3-like, H, wl] for the planar normal
     assert torch.equal(sharding.assemble(planar)[1], img + 100.0)
     assert [sharding.column_shard(4096, r, 8) for r in (0, 7)] == [(0, 512), (3584, 4096)]
+    with pytest.raises(ValueError):  # unequal shards would hang the collective: refused up front
+        sharding.column_shard(4096, 0, 3)
+
+
+def test_plane_slab_views_alias_one_buffer():
+    from atm_raytracer_amd import sharding
+    slab = sharding.PlaneSlab(6, 4, torch.device("cpu"))
+    assert slab.nbytes == 6 * 4 * 84 and set(slab.planes) == set(PLANES)
+    slab.buf.zero_()
+    slab.planes["normal"][2, 5, 3] = 7.0
+    slab.planes["hit_count"][0, 0] = 9
+    assert slab.buf.view(torch.float64)[: 10 * 24][-1] == 7.0
+    assert slab.buf[10 * 24 * 8:].view(torch.int32)[0] == 9
+    pod = slab.device_planes()
+    assert pod.azimuth == slab.buf.data_ptr() and pod.hit_count == slab.buf.data_ptr() + 10 * 24 * 8

@@ -311,3 +311,41 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     tiles = synth.synth_tiles([46], [8], level=301)
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
+def _nested_cylinders(cfg, n, lat=46.53, lon=8.5, r0=4.0, dr=3.0, alpha=0.5):
+    """n concentric translucent cylinders on one spot: a ray through them collects up to 2 n points inside ONE 100 m step."""
+    from atm_raytracer_amd import _abi
+    objs = []
+    for i in range(n):
+        o = _abi.Object()
+        o.kind, o.r1, o.r2, o.height = _abi.OBJ_FRUSTUM, r0 + dr * i, r0 + dr * i, 900.0
+        o.position.latitude, o.position.longitude = lat, lon
+        o.position.altitude_kind, o.position.altitude = _abi.ALT_RELATIVE, 0.0
+        o.color[0], o.color[1], o.color[2], o.color[3] = 0.1 + 0.04 * i, 0.9 - 0.04 * i, 0.5, alpha
+        objs.append(o)
+    cfg.objects = objs
+    return cfg
+
+
+@pytest.mark.parametrize("generator,w,h", [("Rectilinear", 40, 24), ("Fast", 64, 32), ("InterpolatingRectilinear", 64, 32)])
+def test_more_trace_points_in_one_step_than_the_step_list(gpu_ctx, oracle_det, generator, w, h):
+    """20 translucent cylinders nested inside one another 3.3 km ahead: the steps that cross them produce up to 41 trace points
+    (step_result of the reference has no bound, utils.rs:213-282) against the 12 the device keeps in registers — those steps are
+    sorted in HBM (big_step_sort); an interpolating pixel's four lattice corners then hold > 64 points (k_interp_blend_big).
+    Round 1 answered both with ATMRT_ERR_UNSUPPORTED."""
+    from util import frame_stats
+    cfg, tiles = synth.scene("S2", w, h, generator=generator, terrain_alpha=0.5, max_distance=20_000.0, tilt=3.0, fov=8.0)
+    _nested_cylinders(cfg, 20)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    stats = frame_stats(gpu_ctx)
+    assert got["hit_count"].max() > 24, int(got["hit_count"].max())
+    assert stats["big_steps"] > 0, stats
+    if generator == "InterpolatingRectilinear":
+        assert stats["big_blend_pixels"] > 0, stats
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+    # and with an opaque core: the step ends the march, every point of the step is still reported in prop order (utils.rs:279-285)
+    cfg.objects[0].color[3] = 1.0
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert frame_stats(gpu_ctx)["big_steps"] > 0
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))

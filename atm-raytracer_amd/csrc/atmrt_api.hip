@@ -385,6 +385,7 @@ static int upload_terrain(atmrt_ctx* c) {
   if (c->tiles.empty()) {
     tv.lat_min = tv.lon_min = 0;
     tv.n_cells_lat = tv.n_cells_lon = 0;
+    tv.skip_above = 1.0; // no tiles: every lookup is 0 m
     c->tv = tv;
     c->terrain_dirty = false;
     return ATMRT_OK;
@@ -425,6 +426,9 @@ static int upload_terrain(atmrt_ctx* c) {
   tv.lon_min = lon_min;
   tv.n_cells_lat = ncl;
   tv.n_cells_lon = nco;
+  int16_t top = 0;
+  for (int16_t v : mosaic) top = std::max(top, v);
+  tv.skip_above = (double)top + 1.0;
   c->tv = tv;
   c->terrain_dirty = false;
   return ATMRT_OK;
@@ -1025,6 +1029,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->stats.big_steps = counters[6];
   c->stats.big_blend_pixels += counters[7];
   c->stats.retraced_pixels += ws.n_overflow;
+  c->stats.terrain_lookups = counters[10];
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;

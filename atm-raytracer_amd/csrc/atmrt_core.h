@@ -647,6 +647,9 @@ struct TerrainView {
   const TileDesc* tiles;
   const int32_t* cell_tile; // [n_cells_lat][n_cells_lon] -> tile slot or -1
   int32_t lat_min, lon_min, n_cells_lat, n_cells_lon;
+  // max(highest post, 0) + 1 m: a ray sample above it is above the terrain for certain (the bilinear value is a convex
+  // combination of posts up to a few ulps, and 0 m stands for every missing tile), so its lookup cannot change a sign test
+  double skip_above;
 };
 
 // Rust `f as i16` / `f as usize` (saturating, NaN -> 0)

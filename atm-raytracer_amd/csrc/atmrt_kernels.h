@@ -80,8 +80,8 @@ struct PathSegState {
 // [3] scan total of the close lists / pixels that overflowed their slots / cursor of the overflow list, [4] rays whose candidate
 // list overflowed, [5] columns whose candidate list overflowed, [6] steps with more trace points than StepHits holds,
 // [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
-// together (size of the member arena), [9] cursor of that arena
-constexpr int N_COUNTERS = 10;
+// together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march
+constexpr int N_COUNTERS = 12;
 
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
   // MODE 2 may be restricted to a list of pixels (those whose crossings did not fit the slots of the counting march)
   const bool live = pixel_list ? tid < n_list : tid < plane;
   const size_t p = pixel_list ? (live ? pixel_list[tid] : 0) : tid;
-  unsigned long long steps = 0;
+  unsigned long long steps = 0, lookups = 0;
   if (live) {
     const Earth e = earth_for<CALC>(f);
     const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
     const double radius = e.shape_radius;
     const bool straight = f.p.straight_rays != 0;
     const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+    const double skip_above = f.tv.skip_above;
     const bool opaque = f.p.terrain_alpha == 1.0;
     const double alt = *f.alt;
     double direction, elevation;
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
       double lat, lon;
       coords_at_dist(e, c, 0.0, lat, lon);
       double diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
+      lookups++;
       double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh = alt, path_length = 0.0;
       for (int i = 1;; i++) {
@@ -73,8 +75,16 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
         sx = st.x;
         sh = st.h;
         if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
-        coords_at_dist(e, c, sx, lat, lon);
-        double diff1 = sh - terrain_elev_or_zero(f.tv, lat, lon);
+        // A sample above every post of the mosaic is above the terrain, whatever its geodesic point: ray - terrain is positive and
+        // only its SIGN enters the test below (the epilogue rebuilds the bracketing samples in full), so the geodesic point and
+        // the lookup are skipped and any positive number stands for the difference.  Wavefronts are 64 columns of one row: sky
+        // rows leave the terrain's height range together.  NaN heights take the full path.
+        double diff1 = 1.0;
+        if (!(sh > skip_above)) {
+          coords_at_dist(e, c, sx, lat, lon);
+          diff1 = sh - terrain_elev_or_zero(f.tv, lat, lon);
+          lookups++;
+        }
         steps++;
         if (diff0 * diff1 < 0.0) { // utils.rs:222
           if (MODE == 0) {
@@ -119,7 +129,11 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
   }
   if (MODE != 2) {
     steps = wave_sum(steps);
-    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
+    lookups = wave_sum(lookups);
+    if ((threadIdx.x & 63) == 0 && steps) {
+      atomicAdd(&counters[0], steps);
+      atomicAdd(&counters[10], lookups);
+    }
   }
 }
 
@@ -215,6 +229,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
     const bool straight = f.p.straight_rays != 0;
     const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
     const bool terrain_opaque = f.p.terrain_alpha == 1.0;
+    const double skip_above = f.tv.skip_above;
     const double alt = *f.alt;
     double direction, elevation;
     rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
@@ -242,17 +257,27 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         if (chi[q] >= 0.0) x_wake = clo[q] < x_wake ? clo[q] : x_wake;
       double re0 = alt, d0 = 0.0, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh_ = alt, path_length = 0.0;
+      bool have0 = true; // lat0 / lon0 / te0 hold the previous sample's geodesic point and terrain elevation
       for (int i = 1;; i++) {
         RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step);
         path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h);
         sx = st.x;
         sh_ = st.h;
         if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
-        double lat1, lon1;
-        coords_at_dist(e, c, sx, lat1, lon1);
-        double te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
+        // The geodesic point and the terrain lookup of a sample are skipped while nothing can need them: the ray is above every
+        // post of the mosaic (ray - terrain is positive for certain, only its sign enters the crossing test) and no candidate
+        // object's distance interval has been reached (no proximity test at this sample).  If the step turns out to produce
+        // trace points after all, the skipped samples are evaluated then.  Rays without a candidate list test every object at
+        // every sample and never skip.
+        const bool awake = use_cand && sx >= x_wake; // inside (or past the start of) some candidate's interval
+        bool have1 = !use_cand || awake || !(sh_ > skip_above);
+        double lat1 = 0.0, lon1 = 0.0, te1 = 0.0;
+        if (have1) {
+          coords_at_dist(e, c, sx, lat1, lon1);
+          te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
+        }
         m1 = 0u;
-        if (use_cand && sx >= x_wake) { // inside (or past the start of) some candidate's interval
+        if (awake) {
           m1 = close_mask(f, e, lat1, lon1, cand, ncand);
           x_wake = dm_inf(); // next distance of interest: the earliest start among the intervals not yet left behind
           for (int q = 0; q < ncand; q++)
@@ -262,12 +287,8 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         StepHits hits;
         hits.n = 0;
         hits.finish = false;
-        double diff1 = re0 - te0, diff2 = sh_ - te1;
+        double diff1 = have0 ? re0 - te0 : 1.0, diff2 = have1 ? sh_ - te1 : 1.0;
         const bool crossing = diff1 * diff2 < 0.0;
-        if (crossing) {
-          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr);
-          if (terrain_opaque) hits.finish = true;
-        }
         // the objects this step tests, ascending: union of the close lists of its two samples (utils.rs:241-250)
         unsigned m = 0u;
         bool any_object = false;
@@ -278,6 +299,24 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
           any_object = m != 0u;
         } else {
           any_object = f.n_objects != 0;
+        }
+        if ((crossing || any_object) && !(have0 && have1)) { // the step produces trace points: its samples in full after all
+#pragma unroll 1
+          for (int q = 0; q < 2; q++) { // rolled: one more instance of the geodesic code, not two (rare path)
+            if (q == 0 ? have0 : have1) continue;
+            double la, lo;
+            coords_at_dist(e, c, q == 0 ? d0 : sx, la, lo);
+            const double te = terrain_elev_or_zero(f.tv, la, lo);
+            if (q == 0) lat0 = la, lon0 = lo, te0 = te;
+            else lat1 = la, lon1 = lo, te1 = te;
+          }
+          have0 = have1 = true;
+          diff1 = re0 - te0;
+          diff2 = sh_ - te1;
+        }
+        if (crossing) {
+          step_push(hits, diff1 / (diff1 - diff2), -1, nullptr);
+          if (terrain_opaque) hits.finish = true;
         }
         Vec3 pos1 = v3(0.0, 0.0, 0.0), pos2 = pos1;
         LatLonTrig t0{}, t1{};
@@ -331,6 +370,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         count += (unsigned)hits.n;
         if (hits.finish) break;
         lat0 = lat1; lon0 = lon1; te0 = te1; re0 = sh_; d0 = sx; pl0 = path_length;
+        have0 = have1;
         m0 = m1;
       }
     }

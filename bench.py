@@ -7,7 +7,8 @@ A "step" is one full frame of the headline workload (4096x2048 panorama, 3x3 syn
 tiles, simulation_step 100 m, max_distance 200 km, spherical Earth + US-76 refraction) through the C ABI
 (atmrt_generate_device): terrain tiles and parameters are resident in HBM before the timed region, the
 per-pixel result planes stay in HBM.  With N > 1 (one process per GPU under torch.distributed.run) every rank
-marches its own pixel-column tile and the planes are all-gathered over RCCL/xGMI inside the step.
+marches its own pixel-column tile; the tiles' planes (one slab per rank) are all-gathered over RCCL/xGMI by ONE collective and
+permuted into the [H][W] image inside the step.
 
 Prints ONE JSON line (rank 0).  `value` = ray-steps marched by all ranks per second, where a ray-step is one
 sample-pair evaluation of get_single_pixel's loop under the reference's termination rule (utils.rs:211-287).
@@ -81,6 +82,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.width % max(world, 1) != 0:
+        # pixel-column tiles must be equal: all_gather_into_tensor with unequal counts hangs or corrupts (checked before any collective)
+        raise SystemExit(f"bench.py: --width {args.width} is not a multiple of the {world} ranks")
     dist = None
     # under torch.distributed.run the process group (RCCL) is always created, so a 1-rank launch exercises the same
     # all-gather code path as N ranks; a plain `python bench.py` run has no process group
@@ -118,23 +122,19 @@ def main():
     log(f"[rank {rank}] scene ready in {time.perf_counter() - t_setup:.1f} s: {W}x{H}, columns [{c0},{c1}), "
         f"{len(tiles)} tiles of {next(iter(tiles.values())).shape}")
 
-    def planes_for(width):
-        f64 = dict(dtype=torch.float64, device=dev)
-        t = {k: torch.empty((H, width), **f64) for k in ("azimuth", "elevation_angle", "lat", "lon", "distance", "elevation", "path_length")}
-        t["normal"] = torch.empty((3, H, width), **f64)
-        t["hit_count"] = torch.empty((H, width), dtype=torch.int32, device=dev)
-        return t
-
-    local = planes_for(wl)
-    pod = _abi.DevicePlanes(**{k: v.data_ptr() for k, v in local.items()})
-    gathered = None
-    if distributed:
-        gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in local.items()}
+    # the shard's result planes are views of ONE slab; with N > 1 the slabs are all-gathered by a single collective per frame and
+    # permuted into the [H][W] image inside the step (atm_raytracer_amd/sharding.py)
+    from atm_raytracer_amd.sharding import ImageGather, PlaneSlab, gather_hits
+    slab = PlaneSlab(H, wl, dev)
+    local = slab.planes
+    pod = slab.device_planes()
+    via_host = distributed and backend == "gloo"
+    gather = ImageGather(slab, world, via_host=via_host) if distributed else None
 
     gather_events, gather_ms = [], {}
     multi_hit = args.terrain_alpha < 1.0 or args.objects > 0
-    gathered_hits = [None, None, None]
-    from atm_raytracer_amd.sharding import all_gather_hits
+    gathered_hits = [None, None]
+    image = {}
 
     def make_step(generator_name):
         cfg.params.generator = _abi.GENERATORS[generator_name]
@@ -146,20 +146,11 @@ def main():
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 gather_events.append((ev0, ev1))
                 ev0.record()
-                for k, v in local.items():  # one RCCL all-gather per result plane
-                    if backend == "gloo":
-                        host = torch.empty(gathered[k].shape, dtype=v.dtype)
-                        dist.all_gather_into_tensor(host, v.cpu())
-                        gathered[k].copy_(host)
-                    else:
-                        dist.all_gather_into_tensor(gathered[k], v)
-                if multi_hit:  # pixels with several trace points: gather the variable-length lists as well
+                image.update(gather(dist))  # ONE RCCL all-gather of the 88 B/pixel slab + the permutation to [H][W]
+                if multi_hit:  # pixels with several trace points: the variable-length lists as well
                     hits = gen.last_hits_device(H, wl)
                     hits.pop("hit_offset")
-                    hc = local["hit_count"]
-                    if backend == "gloo":
-                        hits, hc = {k: v.cpu() for k, v in hits.items()}, hc.cpu()
-                    gathered_hits[:] = all_gather_hits(hc, hits, world, dist)
+                    gathered_hits[:] = gather_hits(image["hit_count"], hits, world, dist, via_host=via_host)
                 ev1.record()
             return steps, gen.last_timings()
         return step
@@ -265,7 +256,9 @@ def main():
         "roofline": roofline(args.generator, phase),
     }
     if distributed:
-        result["all_gather_ms_per_step"] = gather_ms.get(args.generator)  # inside ms_per_step; 11 planes, 88 B per pixel
+        # inside ms_per_step: one all-gather of the 88 B/pixel slab + the permutation into the [H][W] image (+ the lists of a multi-hit frame)
+        result["all_gather_ms_per_step"] = gather_ms.get(args.generator)
+        result["all_gather_collectives_per_step"] = 1 + (2 if multi_hit else 0)
     if not args.only and args.generator == "Rectilinear":
         # the reference's other two generators on the same workload (secondary lines; `value` above is the per-pixel march)
         e2, m2, ph2 = timed("Fast", args.steps, 1)
@@ -284,16 +277,15 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if distributed and rank == 0 and os.environ.get("ATMRT_BENCH_CHECK_GATHER"):
-        from atm_raytracer_amd.sharding import assemble
-        full = assemble(gathered["distance"].view((world,) + tuple(local["distance"].shape)))
+        full = image["distance"]
         ok = full.shape == (H, W) and torch.equal(full[:, c0:c1].nan_to_num(-1.0), local["distance"].nan_to_num(-1.0))
-        hits = assemble(gathered["hit_count"].view((world,) + tuple(local["hit_count"].shape)))
+        hits = image["hit_count"]
         log(f"gathered image check: shape {tuple(full.shape)}, rank-0 shard matches: {bool(ok)}, hit pixels per rank shard: "
             f"{[int((hits[:, g * wl:(g + 1) * wl] > 0).sum()) for g in range(world)]}")
         if multi_hit:
-            counts, offsets, lists = gathered_hits
-            log(f"gathered trace-point lists: {lists['lat'].shape[0]} points, sum of hit_count {int(counts.sum())}, "
-                f"last offset + count {int(offsets[-1, -1]) + int(counts[-1, -1])}")
+            offsets, lists = gathered_hits
+            log(f"gathered trace-point lists: {lists['lat'].shape[0]} points, sum of hit_count {int(hits.sum())}, "
+                f"last offset + count {int(offsets[-1, -1]) + int(hits[-1, -1])}")
     ctx.close()
     if distributed:
         dist.destroy_process_group()

@@ -339,10 +339,11 @@ def test_more_trace_points_in_one_step_than_the_step_list(gpu_ctx, oracle_det, g
     _nested_cylinders(cfg, 20)
     got = run_gpu(gpu_ctx, cfg, tiles)
     stats = frame_stats(gpu_ctx)
-    assert got["hit_count"].max() > 24, int(got["hit_count"].max())
     assert stats["big_steps"] > 0, stats
-    if generator == "InterpolatingRectilinear":
+    if generator == "InterpolatingRectilinear":  # the blend merges same-class points within one step's distance: few points per pixel
         assert stats["big_blend_pixels"] > 0, stats
+    else:
+        assert got["hit_count"].max() > 24, int(got["hit_count"].max())
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
     # and with an opaque core: the step ends the march, every point of the step is still reported in prop order (utils.rs:279-285)
     cfg.objects[0].color[3] = 1.0

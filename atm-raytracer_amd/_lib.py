@@ -6,7 +6,8 @@ import subprocess
 from . import _abi
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libatmrt.so")
+# ATMRT_LIB: an experimental build of the library (tools/dev_build.sh) instead of the shipped one — development only
+LIB_PATH = os.environ.get("ATMRT_LIB") or os.path.join(CSRC, "libatmrt.so")
 
 _lib = None
 

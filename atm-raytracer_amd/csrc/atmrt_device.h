@@ -146,6 +146,10 @@ static __device__ __forceinline__ Earth earth_for(const Frame& f) {
   e.calc = CALC;
   return e;
 }
+#if defined(ATMRT_DEV_ONLY_SPHERICAL) // development builds (make DEV=1): only the SphericalCalc variants are compiled (1 min instead of 4)
+#define ATMRT_DISPATCH_CALC(calc, STMT) \
+  { constexpr int CALC = 2; STMT; }
+#else
 #define ATMRT_DISPATCH_CALC(calc, STMT)                  \
   switch (calc) {                                        \
     case 0: { constexpr int CALC = 0; STMT; } break;     \
@@ -153,6 +157,7 @@ static __device__ __forceinline__ Earth earth_for(const Frame& f) {
     case 2: { constexpr int CALC = 2; STMT; } break;     \
     default: { constexpr int CALC = 3; STMT; } break;    \
   }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // General tracer (shared part): scenes with objects (and any terrain_alpha).  get_single_pixel in full

@@ -19,6 +19,22 @@ class AtmrtError(RuntimeError):
         self.message = message
 
 
+def source_hash():
+    """sha256 over the sources libatmrt.so is built from (csrc/*.h, csrc/*.hip, include/atmrt.h): profile summaries under
+    profiles/ carry the hash of the sources their counters were collected with, and bench.py only quotes counters whose hash
+    matches the tree it runs from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
+    files.append(os.path.join(os.path.dirname(CSRC), "..", "include", "atmrt.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile libatmrt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:

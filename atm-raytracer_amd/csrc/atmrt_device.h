@@ -199,9 +199,12 @@ static __device__ __forceinline__ void step_push(StepHits& sh, double prop, int 
 static __device__ __forceinline__ bool object_out_of_band(const ObjectDev& o, double re0, double re1) {
   return (re0 < o.vlo && re1 < o.vlo) || (re0 > o.vhi && re1 > o.vhi); // false for NaN: the geometry then decides
 }
-static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2) {
+#if !defined(ATMRT_OBJ_FN) // a translation unit may ask for out-of-line object code (atmrt_march_impl.h does)
+#define ATMRT_OBJ_FN __forceinline__
+#endif
+static __device__ ATMRT_OBJ_FN void step_object_impl(StepHits& sh, const ObjectDev* objects, const uint8_t* textures, int idx, Vec3 pos1, Vec3 pos2) {
   Collision col[4];
-  int nc = object_collision(f.objects[idx], f.textures, pos1, pos2, col);
+  int nc = object_collision(objects[idx], textures, pos1, pos2, col);
   for (int q = 0; q < nc; q++) {
     if (col[q].color[3] == 0.0) continue;
     step_push(sh, col[q].prop, idx, &col[q]);
@@ -210,6 +213,9 @@ static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f,
       break;
     }
   }
+}
+static __device__ __forceinline__ void step_object(StepHits& sh, const Frame& f, int idx, Vec3 pos1, Vec3 pos2) {
+  step_object_impl(sh, f.objects, f.textures, idx, pos1, pos2);
 }
 
 // ---- big steps: more trace points in one step than StepHits keeps ------------------------------------------------------------

@@ -9,6 +9,10 @@
 #define DM_TABLES_LDS atmrt_dm_tables_lds
 __shared__ double atmrt_dm_tables_lds[768];
 #endif
+// In this translation unit the per-object collision code and the proximity filter of a sample are called out of line: they run at
+// a few per cent of the marching steps, and inlined they push the general tracer to 256 VGPRs (2 waves per SIMD; config 5:
+// 559 ms inlined at 2 waves, 507 ms out of line at 3 waves, 680 ms at 4 waves with the spills that needs).
+#define ATMRT_OBJ_FN __attribute__((noinline))
 #include "atmrt_device.h"
 
 namespace atmrt {
@@ -190,20 +194,23 @@ __global__ __launch_bounds__(256) void k_rect_finalize_list(Frame f, uint64_t n_
 // proximity filter of one sample (TerrainData::from_lat_lon, utils.rs:74-80) over the ray's candidates: bit q = cand[q] is close.
 // Any number of close objects fits (the candidate list has at most CAND_CAP = 24 entries), and the union over the two samples
 // of a step is an OR; set bits ascending = object indices ascending.
-static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Earth& e, double lat, double lon, const int* cand,
-                                                      int ncand) {
+static __device__ ATMRT_OBJ_FN unsigned close_mask_impl(const ObjectDev* objects, Earth e, double lat, double lon, const int* cand, int ncand) {
   const LatLonTrig t = latlon_trig(e, lat, lon);
   unsigned m = 0;
   for (int q = 0; q < ncand; q++)
-    if (object_is_close(e, f.objects[cand[q]], t)) m |= 1u << q;
+    if (object_is_close(e, objects[cand[q]], t)) m |= 1u << q;
   return m;
+}
+static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Earth& e, double lat, double lon, const int* cand,
+                                                      int ncand) {
+  return close_mask_impl(f.objects, e, lat, lon, cand, ncand);
 }
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
 // utils.rs:72-88), then the step logic above.
-// 2 waves per SIMD (256 VGPRs): config 5 measured 642 ms; 3 waves (more spills) 700 ms, 4 waves 723 ms
+// 3 waves per SIMD (168 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above)
 #ifndef ATMRT_TRACE_WAVES
-#define ATMRT_TRACE_WAVES 2
+#define ATMRT_TRACE_WAVES 3
 #endif
 template <bool FILL, int CALC, bool CUBIC>
 __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,

@@ -32,27 +32,46 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(generator, seconds_budget=30.0):
-    """The oracle (CPU restatement of the reference, glibc-libm flavour, OpenMP over all host cores) on a
-    bounded sample of the same scene: the full headline frame (Fast / InterpolatingRectilinear) or 1/16 of its pixels (Rectilinear)
-    with identical step / max_distance / field of view (about 10-30 s of CPU work on 16 threads)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(tiles, level):
+    """The oracle (CPU restatement of the reference, glibc-libm flavour, OpenMP) on a bounded sample of the SAME scene and the
+    SAME terrain tiles the GPU ran: Rectilinear on every 4th pixel in x and y (1024x512 = 1/16 of the pixels, same field of view,
+    step and max_distance; ~10-20 s on 16 threads), and the reference's default generator Fast on the whole 4096x2048 frame
+    (~6 s).  A reported baseline, not a target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
     from atm_raytracer_amd import synth
-    w, h = (4096, 2048) if generator != "Rectilinear" else (1024, 512)
-    cfg, tiles = synth.scene("headline", w, h, generator=generator, level=1)
     oracle = Oracle("libm")
     t = oracle.terrain_new(tiles)
     # the GPU box gives one GPU a 16-core share of the host; never fan out over the whole machine
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("ATMRT_CPU_THREADS", "16")))
-    t0 = time.perf_counter()
-    res = oracle.generate(cfg.params, cfg.atmosphere, t, [], cores)
-    dt = time.perf_counter() - t0
-    oracle.terrain_free(t)
-    return {"value": res["ray_steps"] / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
-            "sample": f"headline scene at {w}x{h} px ({generator}), DTED level-1 tiles, {res['ray_steps']} ray-steps in {dt:.2f} s; "
-                      f"oracle/liboracle_libm.so (reference algorithm incl. eager normals), OpenMP",
-            "mpixels_per_s": w * h / dt / 1e6}
+    out = {}
+    try:
+        for generator, (w, h) in (("Rectilinear", (1024, 512)), ("Fast", (4096, 2048))):
+            cfg, _ = synth.scene("headline", w, h, generator=generator, level=301)  # the tiles of the GPU run are used, not these
+            t0 = time.perf_counter()
+            res = oracle.generate(cfg.params, cfg.atmosphere, t, [], cores)
+            dt = time.perf_counter() - t0
+            out[generator] = {"value": res["ray_steps"] / dt, "unit": "ray-steps/s", "mpixels_per_s": w * h / dt / 1e6, "seconds": dt,
+                              "ray_steps": res["ray_steps"], "pixels": f"{w}x{h}"}
+    finally:
+        oracle.terrain_free(t)
+    r = out["Rectilinear"]
+    return {"value": r["value"], "unit": "ray-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"Rectilinear generator, headline scene sampled at {r['pixels']} px = 1/16 of the 4096x2048 pixels (same fov, step, "
+                      f"max_distance), the run's own DTED level-{level} tiles: {r['ray_steps']} ray-steps in {r['seconds']:.2f} s on {cores} "
+                      f"OpenMP threads; oracle/liboracle_libm.so (reference algorithm incl. eager normals per sample)",
+            "mpixels_per_s": r["mpixels_per_s"],
+            "fast": {k: out["Fast"][k] for k in ("value", "unit", "mpixels_per_s", "seconds", "pixels")}}
 
 
 def main():
@@ -152,7 +171,9 @@ def main():
                     hits.pop("hit_offset")
                     gathered_hits[:] = gather_hits(image["hit_count"], hits, world, dist, via_host=via_host)
                 ev1.record()
-            return steps, gen.last_timings()
+            tm = gen.last_timings()
+            tm["terrain_lookups"] = gen.last_stats()["terrain_lookups"]
+            return steps, tm
         return step
 
     def timed(generator_name, k_steps, warmup):
@@ -186,17 +207,43 @@ def main():
             gather_ms[generator_name] = float(g.item())
         return elapsed, marched, phase
 
+    def counters_for(kernel):
+        """rocprofv3 counter summaries committed under profiles/ (counters cannot be read from inside the process): quoted only
+        when they were collected from the sources this library is built from (source_hash) and for this workload."""
+        from atm_raytracer_amd import _lib
+        out = {}
+        if world != 1 or (W, H) != (4096, 2048) or args.scene != "headline" or args.objects or args.terrain_alpha != 1.0:
+            return out
+        for key, name in (("hbm", "pmc_hbm_latest.json"), ("sq", "sq_counters_latest.json")):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            doc = json.load(open(path))
+            meta = doc.get("_meta", {})
+            if meta.get("source_hash") != _lib.source_hash():
+                out[key + "_stale"] = f"profiles/{name} was collected from sources {meta.get('source_hash')}, this tree is {_lib.source_hash()}"
+                continue
+            for k, v in doc.items():
+                if kernel in k:
+                    out[key] = dict(v, file=f"profiles/{name}", source_hash=meta["source_hash"], collected=meta.get("collected"))
+        return out
+
     def roofline(generator_name, phase):
-        """Dominant (longest) kernel of the generator: ITS algorithmic bytes over its mean launch duration from the
-        library's HIP events.  Per-unit figures: the march and the Fast intersect scan are credited
-        8 B per ray-step (the 4 int16 posts of one bilinear lookup, SURVEY.md §8d) plus what they store per pixel;
-        the Fast path kernel stores 16 B per step of every row; the terrain profile reads 8 B and stores 8 B per sample."""
+        """Dominant (longest) kernel of the generator over its mean launch duration from the library's HIP events.
+        HBM side: ALGORITHMIC bytes: 8 B per terrain sample actually evaluated (the 4 int16 posts of one bilinear
+        lookup; the march skips the samples of rays above every post) + what the kernel stores per pixel; the Fast
+        scan is credited 8 B per ray-step, the path kernel 16 B per step of every row, the terrain profile 16 B per sample.
+        Compute side (k_rect_march is FP64-VALU bound, not HBM bound): VALU lane-instructions per second against the FP64 issue
+        peak (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz; x2 = the 78.6 TFLOP/s vector peak counted in FMAs), with the
+        instructions per ray-step from the committed SQ-counter passes of this same command when they match this build."""
         mean = lambda k: float(np.mean([p[k] for p in phase]))
         steps_per_launch = mean("ray_steps")
+        lookups = mean("terrain_lookups")
+        hits = float((local["hit_count"] > 0).sum().item())  # recorded crossings of the last frame (opaque terrain: one per hit pixel)
         n_t = float(int(np.ceil(cfg.params.frame.max_distance / cfg.params.simulation_step)))  # samples per ray (utils.rs:191-196)
         n_path = n_t + 3.0                                                                      # path elements per row (utils.rs:160-170)
         per_kernel = {
-            "march_ms": ("k_rect_march", 8.0 * steps_per_launch + (8 + 8 + 4 + 4) * wl * H),
+            "march_ms": ("k_rect_march", 8.0 * lookups + (8 + 8 + 4 + 4) * wl * H + 32.0 * hits),
             "intersect_ms": ("k_fast_intersect", 8.0 * steps_per_launch + 8.0 * wl * H),
             "paths_ms": ("k_fast_paths", 16.0 * n_path * H),
             "profile_ms": ("k_terrain_profile", 16.0 * n_t * wl),
@@ -206,37 +253,32 @@ def main():
         kernel, algo_bytes = per_kernel[key]
         ms = mean(key)
         achieved = algo_bytes / (ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
-        if os.path.exists(pmc_file) and world == 1 and (W, H) == (4096, 2048):
-            # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (counters cannot be read from inside the process); FETCH_SIZE doubled per the gfx950 note
-            pmc = json.load(open(pmc_file))
-            for name, v in pmc.items():
-                if kernel in name:
-                    traffic, traffic_src = v.get("hbm_bytes_per_frame_fetch_x2", v["hbm_bytes_per_launch_fetch_x2"]), "profiles/pmc_hbm_latest.json"
-        out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": ms,
-               "algorithmic_bytes_per_launch": algo_bytes,
-               "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
-               "all_kernels": {per_kernel[k][0]: {"ms": mean(k), "algorithmic_GBps": per_kernel[k][1] / (mean(k) * 1e-3) / 1e9}
-                               for k in keys if mean(k) > 0}}
-        sq_file = os.path.join(ROOT, "profiles", "r01", "sq_counters_v9.json")
-        if os.path.exists(sq_file):
-            # the compute side of the roofline, from the committed rocprofv3 SQ-counter passes of this command: fraction of
-            # cycles the SIMDs' VALU pipes are busy (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles) and active lanes
-            for name, v in json.load(open(sq_file)).items():
-                if kernel in name:
-                    ipr = v.get("valu_lane_instructions_per_ray_step")
-                    out["valu"] = {"busy_frac": v["valu_busy_frac"], "lane_utilisation": v["lane_utilisation"],
-                                   "valu_lane_instructions_per_ray_step": ipr,
-                                   # live rate of this run against the FP64 issue peak (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz =
-                                   # 3.93e13 lane-instructions/s, i.e. the 78.6 TFLOP/s FP64 vector peak counted in FMAs)
-                                   "lane_instructions_per_s": (ipr * steps_per_launch / (ms * 1e-3)) if ipr else None,
-                                   "fp64_issue_peak_per_s": FP64_ISSUE_PEAK,
-                                   "frac_of_fp64_issue_peak": (ipr * steps_per_launch / (ms * 1e-3) / FP64_ISSUE_PEAK) if ipr else None,
-                                   "source": "profiles/r01/sq_counters_v9.json",
-                                   "note": "k_rect_march is FP64-issue bound (12 n(h) evaluations per RK4 step, each a pow and a Ciddor compressibility term), not HBM bound"}
+        cached = counters_for(kernel)
+        hbm_c = cached.get("hbm")
+        traffic = hbm_c.get("hbm_bytes_per_frame_fetch_x2", hbm_c.get("hbm_bytes_per_launch_fetch_x2")) if hbm_c else None
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+               "traffic_source": {"cached": True, "file": hbm_c["file"], "source_hash": hbm_c["source_hash"], "collected": hbm_c.get("collected")} if hbm_c else cached.get("hbm_stale")}
+        out = dict(hbm)
+        sq = cached.get("sq")
+        ipr = sq.get("valu_lane_instructions_per_ray_step") if sq else None
+        if kernel == "k_rect_march" and ipr:
+            rate = ipr * steps_per_launch / (ms * 1e-3)
+            out = {"bound": "fp64_valu", "achieved": 2.0 * rate / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                   "frac": rate / FP64_ISSUE_PEAK, "traffic": traffic,
+                   "note": "FP64-issue bound: every VALU lane-instruction counted as one FMA slot (2 flop) against the 78.6 TFLOP/s vector "
+                           "peak; achieved = instructions per ray-step (cached SQ counters of this build) x live ray-steps/s",
+                   "valu": {"cached": True, "file": sq["file"], "source_hash": sq["source_hash"], "collected": sq.get("collected"),
+                            "valu_lane_instructions_per_ray_step": ipr, "busy_frac": sq.get("valu_busy_frac"),
+                            "lane_utilisation": sq.get("lane_utilisation"), "lane_instructions_per_s": rate,
+                            "fp64_issue_peak_per_s": FP64_ISSUE_PEAK},
+                   "hbm": hbm}
+        elif "sq_stale" in cached:
+            out["valu"] = {"stale": cached["sq_stale"]}
+        out.update({"kernel": kernel, "kernel_ms": ms, "terrain_samples_per_launch": lookups if kernel == "k_rect_march" else None,
+                    "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
+                    "all_kernels": {per_kernel[k][0]: {"ms": mean(k), "algorithmic_GBps": per_kernel[k][1] / (mean(k) * 1e-3) / 1e9}
+                                    for k in keys if mean(k) > 0}})
         return out
 
     elapsed, marched, phase = timed(args.generator, args.steps, args.warmup)
@@ -271,7 +313,7 @@ def main():
                                                "note": "lattice of Fast-style pixels + 4-corner blend (interpolating_rectilinear.rs)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(args.generator)
+            result["cpu_baseline"] = cpu_baseline(tiles, args.dted_level)
         except Exception as exc:  # the oracle is a checker, never a fallback: report, do not hide
             result["cpu_baseline"] = {"value": None, "error": repr(exc)}
     if rank == 0:

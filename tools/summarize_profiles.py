@@ -47,6 +47,15 @@ def bench_line(path):
     return None
 
 
+def meta(tag):
+    """What bench.py checks before quoting these counters: the hash of the library sources they were collected from."""
+    import datetime
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from atm_raytracer_amd import _lib
+    return {"source_hash": _lib.source_hash(), "collected": datetime.date.today().isoformat(), "tag": tag,
+            "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline --only --generator G (tools/collect_profiles.sh)"}
+
+
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     os.makedirs(dst, exist_ok=True)
@@ -78,6 +87,7 @@ def main():
             hbm[k]["launches_per_frame"] = per_frame
             hbm[k]["hbm_bytes_per_frame_fetch_x2"] = hbm[k]["hbm_bytes_per_launch_fetch_x2"] * per_frame
     if hbm:
+        hbm["_meta"] = meta(tag)
         for p in (os.path.join(dst, f"pmc_hbm_summary_{tag}.json"), os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_hbm_latest.json")):
             json.dump(hbm, open(p, "w"), indent=1, sort_keys=True)
 
@@ -106,7 +116,9 @@ def main():
                 v["launches_per_frame"] = per_frame
                 v["valu_lane_instructions_per_ray_step"] = v["SQ_INSTS_VALU"] * per_frame * 64.0 * v["lane_utilisation"] / n
     if sq:
-        json.dump(sq, open(os.path.join(dst, f"sq_counters_{tag}.json"), "w"), indent=1, sort_keys=True)
+        sq["_meta"] = meta(tag)
+        for p in (os.path.join(dst, f"sq_counters_{tag}.json"), os.path.join(os.path.dirname(dst.rstrip("/")), "sq_counters_latest.json")):
+            json.dump(sq, open(p, "w"), indent=1, sort_keys=True)
     print(f"kernels: hbm {len(hbm)}, sq {len(sq)}; written to {dst} with tag {tag}")
 
 

@@ -10,6 +10,10 @@
 //   k_fast_intersect  phase C: sign-change scan of get_single_pixel     (utils.rs:211-240)
 //   k_fast_finalize   TracePoint at the bracketing samples only   (utils.rs:108-125, 15-40)
 // Rectilinear generator (rectilinear.rs:102-186): k_rect_march, one ray per lane.
+// The per-object collision code is called out of line in this translation unit as well (only k_fast_trace uses it): inlined it
+// takes the Fast tracer to 256 VGPRs / 2 waves per SIMD; out of line at 3 waves config 5 runs 26.0 -> 23.4 ms (Fast) and
+// 73.4 -> 67.7 ms (InterpolatingRectilinear); 4 waves 26.9 ms.
+#define ATMRT_OBJ_FN __attribute__((noinline))
 #include "atmrt_device.h"
 #include "atmrt_render.h"
 
@@ -424,8 +428,11 @@ __global__ __launch_bounds__(256) void k_close_objects(Frame f, const double* __
 // other steps are a handful of vector instructions per row (one coalesced load of the ray elevations, which k_paths_transpose
 // lays out sample-major for this kernel).  Inside an object cell a lane joins the geometry only if its segment enters the
 // height band of an object (object_out_of_band).
+#ifndef ATMRT_FAST_TRACE_WAVES
+#define ATMRT_FAST_TRACE_WAVES 3
+#endif
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_fast_trace(Frame f, const double* __restrict__ prof,
+__global__ __launch_bounds__(256, ATMRT_FAST_TRACE_WAVES) void k_fast_trace(Frame f, const double* __restrict__ prof,
                                                     const double* __restrict__ plat, const double* __restrict__ plon,
                                                     const uint32_t* __restrict__ ccount,
                                                     const uint64_t* __restrict__ coffset,

@@ -104,7 +104,7 @@ struct atmrt_ctx {
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
       d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev, d_step_prop,
-      d_blend_arena;
+      d_blend_arena, d_object_rays;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -703,6 +703,7 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->list_step = nullptr;
   ws->list_pixel = nullptr;
   ws->step_prop = nullptr;
+  ws->object_rays = nullptr;
   return ATMRT_OK;
 }
 
@@ -772,8 +773,16 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (general) {
+    // Rectilinear with scene objects: the lean march first (it leaves the rays that can meet an object to the general tracer and
+    // lists them), then the tracer over that list
+    HIP_TRY(c, c->d_object_rays.reserve((size_t)f.wl * f.h * sizeof(uint32_t)));
+    ws.object_rays = c->d_object_rays.as<uint32_t>();
     HIP_TRY(c, hipEventRecord(ev[4], s));
     launch_trace_count(f, ws, dense, s);
+    uint64_t cnt[N_COUNTERS] = {};
+    HIP_TRY(c, hipMemcpyAsync(cnt, ws.counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    launch_rect_trace_objects(f, ws, dense, cnt[11], s);
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (fast) {
@@ -1030,6 +1039,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->stats.big_blend_pixels += counters[7];
   c->stats.retraced_pixels += ws.n_overflow;
   c->stats.terrain_lookups = counters[10];
+  c->stats.object_rays = counters[11];
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;

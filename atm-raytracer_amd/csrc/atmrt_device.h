@@ -93,31 +93,50 @@ constexpr int CAND_CAP = 24;
 // difference |x/R - phi_j| and must stay below 2 asin(reach / 2(R + elev)); flat map: the along-track coordinate differs by
 // less than reach.  The bounds are widened by 0.1 % + 1 mm (and to the whole ray for reaches above 1 % of the radius or
 // objects below the surface by more than the radius), so they are a superset like the list itself.
+// One object against one ray: can it ever be close, and (want_interval) at which stepper distances [lo, hi]?
+template <int CALC>
+static __device__ __forceinline__ bool candidate_interval(const Earth& e, const DirCalc& c, Vec3 nrm, const ObjectDev& o, bool want_interval,
+                                                          double& lo, double& hi) {
+  Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
+  double dperp = dm_fabs(dot(rel, nrm));
+  double reach = dm_sqrt(o.close2) + 1.0e-3;
+  if (!(dperp <= reach)) return false;
+  if (want_interval) {
+    double along, half = reach * 1.001 + 1.0e-3;
+    if (CALC == 2) {
+      along = e.calc_radius * dm_atan2(dot(o.pos, c.dir), dot(o.pos, c.pos));
+      if (o.elev < 0.0) half = half * (e.cart_radius / (e.cart_radius + o.elev));
+      if (!(reach < 0.01 * e.cart_radius) || !(half > 0.0) || !(e.calc_radius == e.cart_radius)) half = dm_inf();
+    } else {
+      along = dot(rel, c.dir);
+    }
+    lo = along - half;
+    hi = along + half;
+    if (!(lo <= hi)) lo = -dm_inf(), hi = dm_inf(); // NaN anywhere: no restriction
+  }
+  return true;
+}
+template <int CALC>
+static __device__ __forceinline__ bool candidates_supported(const Earth& e) {
+  return (CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0);
+}
+template <int CALC>
+static __device__ __forceinline__ Vec3 track_normal(const DirCalc& c) { // unit normal of the track plane / line
+  return CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0);
+}
 template <int CALC, int CAP>
 static __device__ __forceinline__ bool ray_candidates(const Frame& f, const Earth& e, const DirCalc& c, int* cand, int& n,
                                                       double* lo = nullptr, double* hi = nullptr) {
   n = 0;
-  if (!((CALC == 2 && e.cart == 1) || (CALC == 0 && e.cart == 0))) return false;
-  Vec3 nrm = CALC == 2 ? cross(c.pos, c.dir) : v3(-c.dir.y, c.dir.x, 0.0); // unit normal of the track plane / line
+  if (!candidates_supported<CALC>(e)) return false;
+  const Vec3 nrm = track_normal<CALC>(c);
   for (int j = 0; j < f.n_objects; j++) {
-    const ObjectDev& o = f.objects[j];
-    Vec3 rel = CALC == 2 ? o.pos : v3(o.pos.x - c.pos.x, o.pos.y - c.pos.y, 0.0);
-    double dperp = dm_fabs(dot(rel, nrm));
-    double reach = dm_sqrt(o.close2) + 1.0e-3;
-    if (dperp <= reach) {
+    double l = 0.0, h = 0.0;
+    if (candidate_interval<CALC>(e, c, nrm, f.objects[j], lo != nullptr, l, h)) {
       if (n >= CAP) return false;
       if (lo) {
-        double along, half = reach * 1.001 + 1.0e-3;
-        if (CALC == 2) {
-          along = e.calc_radius * dm_atan2(dot(o.pos, c.dir), dot(o.pos, c.pos));
-          if (o.elev < 0.0) half = half * (e.cart_radius / (e.cart_radius + o.elev));
-          if (!(reach < 0.01 * e.cart_radius) || !(half > 0.0) || !(e.calc_radius == e.cart_radius)) half = dm_inf();
-        } else {
-          along = dot(rel, c.dir);
-        }
-        lo[n] = along - half;
-        hi[n] = along + half;
-        if (!(lo[n] <= hi[n])) lo[n] = -dm_inf(), hi[n] = dm_inf(); // NaN anywhere: no restriction
+        lo[n] = l;
+        hi[n] = h;
       }
       cand[n++] = j;
     }

@@ -80,7 +80,8 @@ struct PathSegState {
 // [3] scan total of the close lists / pixels that overflowed their slots / cursor of the overflow list, [4] rays whose candidate
 // list overflowed, [5] columns whose candidate list overflowed, [6] steps with more trace points than StepHits holds,
 // [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
-// together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march
+// together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march,
+// [11] rays of a scene with objects that the lean march left to the general tracer
 constexpr int N_COUNTERS = 12;
 
 // Scratch owned by the context, sized for the current frame.
@@ -121,6 +122,7 @@ struct Workspace {
   uint32_t* clist;        // object indices, ascending per sample
   int32_t* col_cand;      // [wl][64] objects that can be close to any sample of the column (ascending), and ...
   int32_t* col_ncand;     // ... their number; -1 = no list, test every object
+  uint32_t* object_rays;  // Rectilinear, scenes with objects: pixels the lean march left to the general tracer
   double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
 };
@@ -197,6 +199,7 @@ void launch_draw_image(size_t n_pixels, const atmrt_coloring_t& col, double terr
                        uint8_t* rgb, hipStream_t stream);
 
 void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
+void launch_rect_trace_objects(const Frame& f, Workspace& ws, const DensePlanes& out, uint64_t n_rays, hipStream_t stream);
 void launch_rect_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                             hipStream_t stream);
 void launch_dense_from_packed(const Frame& f, Workspace& ws, const PackedHits& packed, const DensePlanes& dense, int fast_angles,

@@ -22,6 +22,8 @@ namespace atmrt {
 // Rectilinear generator: one ray per lane — per-step geodesic point, bilinear terrain gather
 // (4 int16 posts = 8 B), sign test, RK4 step (rectilinear.rs:161-185 driving utils.rs:201-289).
 // MODE 0: opaque, write the dense first hit.  MODE 1: count.  MODE 2: write packed trace points.
+// MODE 3: scenes with objects — count like MODE 1 (slots pixel-indexed, in the general tracer's arena), but give up on a ray
+// (hit_count = OBJECT_RAY) at the first step that can involve an object; those rays are traced by k_rect_trace afterwards.
 // ---------------------------------------------------------------------------------------------
 // The march only records WHERE the ray crossed the terrain (step index + ray elevation and path
 // length at the two bracketing samples); k_rect_finalize rebuilds the geodesic points, the four
@@ -33,6 +35,18 @@ namespace atmrt {
 #ifndef ATMRT_MARCH_WAVES
 #define ATMRT_MARCH_WAVES 4
 #endif
+// Scenes with objects (MODE 3).  The general tracer pays for its generality at every step (candidate lists, step lists,
+// collision geometry: 3 waves per SIMD), yet a step can only involve an object while the ray is inside the distance interval of a
+// candidate object AND its segment enters that object's height band — for most rays never.  So the lean march runs first, with one
+// candidate list PER WAVEFRONT in LDS: the wavefront's 64 rays are adjacent pixels of one row, they advance through the same
+// distances x (x = 0 + step + ... is the same sum for every ray), and the list holds, for every object that is a candidate of any
+// of its rays, the union of those rays' intervals [lo, hi] and the object's height band.  The per-step test is a wave-uniform
+// scan of that list, executed only between the list's next interval start and the end of the intervals it is inside.  The union
+// is a superset of every ray's own candidates (same candidate_interval as ray_candidates), the band test is the tracer's own
+// (object_out_of_band), so a ray that is never flagged has provably no step with an object: its terrain-only result is final.
+constexpr uint32_t OBJECT_RAY = 0xffffffffu; // hit_count of a ray left to k_rect_trace
+constexpr int WAVE_CAND = 96;                // entries of a wavefront's list; more: every ray of the wavefront is left to the tracer
+
 template <int MODE, int CALC, bool CUBIC>
 __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
@@ -65,8 +79,50 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
     unsigned count = 0;
     int first = -1;
     uint64_t k = MODE == 2 ? hit_offset[p] : 0;
+    bool object_ray = false; // MODE 3: this ray is left to the general tracer
+    int w_n = 0;             // MODE 3: entries of the wavefront's candidate list
+    double x_wake = dm_inf();
+    __shared__ double w_lo[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1], w_hi[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1],
+        w_vlo[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1], w_vhi[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1];
+    const int wv = threadIdx.x >> 6;
+    if (MODE == 3) {
+      if (!candidates_supported<CALC>(e)) {
+        object_ray = true; // no geometric pre-filter for this earth model: every ray tests every object
+      } else {
+        const Vec3 nrm = track_normal<CALC>(c);
+        for (int j = 0; j < f.n_objects; j++) { // wave-uniform loop; the object's fields are scalar loads
+          double lo = dm_inf(), hi = -dm_inf();
+          double l, h;
+          if (candidate_interval<CALC>(e, c, nrm, f.objects[j], true, l, h)) lo = l, hi = h;
+          unsigned long long holders = __ballot(lo <= hi); // the active lanes for which the object is a candidate
+          if (holders) {
+            double wlo = dm_inf(), whi = -dm_inf();
+            for (; holders; holders &= holders - 1) { // union of their intervals (reads active lanes only)
+              const int src = __builtin_ctzll(holders);
+              const double l2 = __shfl(lo, src, 64), h2 = __shfl(hi, src, 64);
+              wlo = l2 < wlo ? l2 : wlo;
+              whi = h2 > whi ? h2 : whi;
+            }
+            lo = wlo;
+            hi = whi;
+            if (w_n < WAVE_CAND) {
+              if ((threadIdx.x & 63) == 0) {
+                w_lo[wv][w_n] = lo;
+                w_hi[wv][w_n] = hi;
+                w_vlo[wv][w_n] = f.objects[j].vlo;
+                w_vhi[wv][w_n] = f.objects[j].vhi;
+              }
+            }
+            w_n++;
+          }
+        }
+        if (w_n > WAVE_CAND) object_ray = true; // the list overflowed: leave the whole wavefront to the tracer
+        for (int q = 0; q < w_n && q < WAVE_CAND; q++) // first interval that is not behind the start
+          if (w_hi[wv][q] >= 0.0) x_wake = w_lo[wv][q] < x_wake ? w_lo[wv][q] : x_wake;
+      }
+    }
     // first sample (PathIterator::next at the start state); the reference would panic on an empty stream
-    if (!(0.0 > max_dist || alt < -1000.0)) {
+    if (!(0.0 > max_dist || alt < -1000.0) && !object_ray) {
       double lat, lon;
       coords_at_dist(e, c, 0.0, lat, lon);
       double diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
@@ -79,6 +135,27 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
         sx = st.x;
         sh = st.h;
         if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
+        if (MODE == 3 && sx >= x_wake) { // wave-uniform: x and the list are the same for every ray of the wavefront
+          // this step (the samples at x - step and x) against the list: inside an entry's interval and inside its height band ->
+          // the step may involve that object: the ray goes to the tracer.  Next wake: the nearest interval start ahead, or the
+          // next step while an interval is being crossed.
+          const double x_prev = sx - step * 1.000001; // a little before the older sample (its x is sx - step up to rounding)
+          double next = dm_inf();
+          const int n_e = w_n < WAVE_CAND ? w_n : WAVE_CAND;
+          for (int q = 0; q < n_e; q++) {
+            const double lo = w_lo[wv][q], hi = w_hi[wv][q];
+            if (hi < x_prev) continue;               // behind the step
+            if (lo > sx) {                           // ahead of it
+              next = lo < next ? lo : next;
+              continue;
+            }
+            next = sx;                               // being crossed: look again at the next step
+            const double vlo = w_vlo[wv][q], vhi = w_vhi[wv][q];
+            if (!((re0 < vlo && sh < vlo) || (re0 > vhi && sh > vhi))) object_ray = true; // object_out_of_band is false
+          }
+          x_wake = next;
+          if (object_ray) break;
+        }
         // A sample above every post of the mosaic is above the terrain, whatever its geodesic point: ray - terrain is positive and
         // only its SIGN enters the test below (the epilogue rebuilds the bracketing samples in full), so the geodesic point and
         // the lookup are skipped and any positive number stands for the difference.  Wavefronts are 64 columns of one row: sky
@@ -114,6 +191,16 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
             rec.re1[k] = sh;
             rec.pl1[k] = path_length;
             k++;
+          } else if (MODE == 3) {
+            if (count < (unsigned)RECT_SLOTS) { // the general tracer's slot arena, pixel-indexed; list_pixel carries its color_tag array
+              const size_t q = p * RECT_SLOTS + count;
+              list_step[q] = (uint32_t)(i - 1);
+              list_pixel[q] = ATMRT_COLOR_TERRAIN;
+              rec.re0[q] = re0;
+              rec.pl0[q] = pl0;
+              rec.re1[q] = sh;
+              rec.pl1[q] = path_length;
+            }
           }
           count++;
           if (opaque) break; // utils.rs:237-239, 283-285
@@ -123,13 +210,17 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
         pl0 = path_length;
       }
     }
-    if (MODE != 2) {
+    if (MODE == 3 && object_ray) { // nothing of this ray counts: k_rect_trace starts it again
+      out.hit_count[p] = OBJECT_RAY;
+      steps = 0;
+      lookups = 0;
+    } else if (MODE != 2) {
       out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
       out.elevation_angle[p] = dm_to_degrees(elevation);
       out.hit_count[p] = count;
     }
     if (MODE == 0) hit_step[p] = first;
-    if (MODE == 1 && count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
+    if ((MODE == 1 || (MODE == 3 && !object_ray)) && count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
   }
   if (MODE != 2) {
     steps = wave_sum(steps);
@@ -472,14 +563,35 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
 }
 
 
+// the rays k_rect_march<3> left to the tracer, collected into a list (order irrelevant: every ray is independent); counters[11] = their number
+static __global__ __launch_bounds__(256) void k_collect_object_rays(size_t n, const uint32_t* __restrict__ hit_count,
+                                                                    uint32_t* __restrict__ list, unsigned long long* __restrict__ counters) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && hit_count[p] == OBJECT_RAY) list[atomicAdd(&counters[11], 1ull)] = (uint32_t)p;
+}
+
+// Scenes with objects, counting pass, phase 1: the lean march over every pixel (terrain crossings into the tracer's slot arena,
+// rays that can meet an object flagged and listed); phase 2 (launch_rect_trace_objects_t, after the host has read the list's
+// length) traces the listed rays with the general tracer.
 template <bool CUBIC>
 void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<3, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
+                                                        ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
+                                                        (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u));
+  hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
+                     (unsigned long long*)ws.counters);
+}
+template <bool CUBIC>
+void launch_rect_trace_objects_t(const Frame& f, Workspace& ws, const DensePlanes& out, uint64_t n_rays, hipStream_t stream) {
+  if (!n_rays) return;
+  size_t n = (size_t)f.wl * f.h;
+  RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv((size_t)n_rays, 256)), dim3(256), 0, stream, f, out,
                                                         (const uint64_t*)nullptr, ws.slot_packed, slots, ws.slot_step,
                                                         ws.slot_pixel, (unsigned long long*)ws.counters,
-                                                        (const uint32_t*)nullptr, 0u, (double*)nullptr));
+                                                        (const uint32_t*)ws.object_rays, (uint32_t)n_rays, (double*)nullptr));
 }
 
 // Trace points kept in the slot arena by the counting pass of k_rect_trace, moved to their places in the pixel-ordered list
@@ -551,6 +663,7 @@ void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, co
   template void launch_multi_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,         \
                                            hipStream_t);                                                                      \
   template void launch_rect_trace_count_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);                  \
+  template void launch_rect_trace_objects_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t);      \
   template void launch_rect_trace_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,    \
                                                 hipStream_t);
 

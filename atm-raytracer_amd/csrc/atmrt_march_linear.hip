@@ -8,6 +8,7 @@ ATMRT_INSTANTIATE_MARCH(false)
 extern template void launch_rect_march_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t, hipEvent_t);
 extern template void launch_multi_fill_t<true>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
 extern template void launch_rect_trace_count_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
+extern template void launch_rect_trace_objects_t<true>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t);
 extern template void launch_rect_trace_fill_t<true>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
 
 void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
@@ -22,6 +23,10 @@ void launch_multi_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
 void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
   if (f.atm_cubic) launch_rect_trace_count_t<true>(f, ws, out, stream);
   else launch_rect_trace_count_t<false>(f, ws, out, stream);
+}
+void launch_rect_trace_objects(const Frame& f, Workspace& ws, const DensePlanes& out, uint64_t n_rays, hipStream_t stream) {
+  if (f.atm_cubic) launch_rect_trace_objects_t<true>(f, ws, out, n_rays, stream);
+  else launch_rect_trace_objects_t<false>(f, ws, out, n_rays, stream);
 }
 void launch_rect_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                             hipStream_t stream) {

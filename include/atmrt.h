@@ -280,6 +280,8 @@ typedef struct atmrt_frame_stats {
                                  above the highest post of the mosaic (+ 1 m) is above the terrain for certain, so its geodesic
                                  point and lookup are not evaluated — every ODE step, sign test and result stays the same;
                                  ray_steps keeps counting every step */
+  uint64_t object_rays;       /* Rectilinear, scenes with objects: rays that came within a candidate object's distance interval
+                                 and height band, traced by the general tracer; the others keep the lean march's result */
 } atmrt_frame_stats_t;
 int atmrt_last_stats(atmrt_ctx* ctx, atmrt_frame_stats_t* out);
 /* Fault injection for tests of the error paths: the next atmrt_generate / atmrt_generate_device on ctx runs its kernels and then

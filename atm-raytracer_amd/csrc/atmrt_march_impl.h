@@ -169,11 +169,7 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
         steps++;
         if (diff0 * diff1 < 0.0) { // utils.rs:222
           if (MODE == 0) {
-            first = i - 1;
-            rec.re0[p] = re0;
-            rec.pl0[p] = pl0;
-            rec.re1[p] = sh;
-            rec.pl1[p] = path_length;
+            first = i - 1; // the record is stored after the loop: opaque terrain ends the march here, the four values stay as they are
           } else if (MODE == 1) {
             if (count < (unsigned)RECT_SLOTS) { // slot arrays come in through list_step / rec, slot-major
               const size_t q = (size_t)count * plane + p;
@@ -208,6 +204,12 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
         diff0 = diff1;
         re0 = sh;
         pl0 = path_length;
+      }
+      if (MODE == 0 && first >= 0) { // ray elevation and path length at the two samples that bracket the crossing
+        rec.re0[p] = re0;
+        rec.pl0[p] = pl0;
+        rec.re1[p] = sh;
+        rec.pl1[p] = path_length;
       }
     }
     if (MODE == 3 && object_ray) { // nothing of this ray counts: k_rect_trace starts it again

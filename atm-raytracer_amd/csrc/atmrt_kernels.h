@@ -149,7 +149,7 @@ struct LatticeResult { // the lattice frame's packed result
   const uint32_t* px_steps;
   int32_t nd, ne;
 };
-struct BlendArena { // member lists of the pixels k_interp_blend_big blends (more than 64 corner points)
+struct BlendArena { // member lists of the pixels k_interp_blend_big blends (more than 4 corner points together)
   uint64_t* k;
   double* dist;
   uint32_t* group;

@@ -917,8 +917,14 @@ static __device__ FullTP tp_interpolate(const FullTP& a, const FullTP& b, double
   return r;
 }
 
-constexpr int INTERP_MEMBERS = 64; // trace points of the four corner pixels together that the in-register member list holds;
-                                    // pixels with more are blended by k_interp_blend_big over a member arena in HBM
+// Trace points of the four corner pixels together that the in-register member list holds; pixels with more are blended by
+// k_interp_blend_big over a member arena in HBM.  4 = no middle instance: a 64-member in-register instance (round 1) cost 230-274
+// VGPRs and 0.5-1 KB of scratch for its arrays, the arena instance needs 48-148 VGPRs and none — interpolating frame at
+// terrain_alpha 0.5: 33.3 ms with 64, 26.5 (32), 20.7 (16), 20.1 ms with 4; config 5: 67.6 -> 53.5 ms.
+#ifndef ATMRT_INTERP_MEMBERS
+#define ATMRT_INTERP_MEMBERS 4
+#endif
+constexpr int INTERP_MEMBERS = ATMRT_INTERP_MEMBERS;
 
 // interpolate_trace_points :267-337 on the group's corner members (index -1 = None)
 static __device__ bool interp_group(const LatticeResult& lr, const uint64_t* member_k, const int e[4], double re, double rd,
@@ -1016,9 +1022,9 @@ static __device__ __forceinline__ unsigned blend_members(const LatticeResult& lr
 
 // interpolate :395-418 with collect_trace_points :213-243 and match_sequence :245-265
 // CAP = 4: the pixels whose four lattice corners hold at most four trace points together (nearly all of them) — the member
-// arrays are four registers wide; CAP = INTERP_MEMBERS: the others.  Both instances run over the whole image, each pixel is
-// blended by exactly one of them; the CAP = 4 instance also writes what does not depend on the members (referenced marks,
-// blended angles).
+// arrays are four registers wide; it also writes what does not depend on the members (referenced marks, blended angles) and sizes
+// the arena of k_interp_blend_big, which blends the others.  (A middle instance, CAP = INTERP_MEMBERS > 4, exists in the template
+// but is not launched: see INTERP_MEMBERS.)
 template <bool FILL, int CAP>
 __global__ __launch_bounds__(256) void k_interp_blend(Frame f, InterpBuffers ib, LatticeResult lr, DensePlanes out,
                                                       const uint64_t* __restrict__ hit_offset, PackedHits packed,
@@ -1119,13 +1125,15 @@ void launch_interp_blend(const Frame& f, Workspace& ws, const InterpBuffers& ib,
   if (fill) {
     hipLaunchKernelGGL((k_interp_blend<true, 4>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
                        (unsigned long long*)ws.counters);
-    hipLaunchKernelGGL((k_interp_blend<true, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
-                       (unsigned long long*)ws.counters);
+    if (INTERP_MEMBERS > 4)
+      hipLaunchKernelGGL((k_interp_blend<true, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, ws.hit_offset, packed,
+                         (unsigned long long*)ws.counters);
   } else {
     hipLaunchKernelGGL((k_interp_blend<false, 4>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr, packed,
                        (unsigned long long*)ws.counters);
-    hipLaunchKernelGGL((k_interp_blend<false, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr,
-                       packed, (unsigned long long*)ws.counters);
+    if (INTERP_MEMBERS > 4)
+      hipLaunchKernelGGL((k_interp_blend<false, INTERP_MEMBERS>), grid, dim3(256), 0, stream, f, ib, lr, dense, (const uint64_t*)nullptr,
+                         packed, (unsigned long long*)ws.counters);
   }
 }
 void launch_interp_blend_big(const Frame& f, Workspace& ws, const InterpBuffers& ib, const LatticeResult& lr, bool fill,

@@ -275,7 +275,8 @@ typedef struct atmrt_frame_stats {
   uint64_t unlisted_columns;  /* Fast / InterpolatingRectilinear: columns with more candidates than the per-column list (64) */
   uint64_t retraced_pixels;   /* Rectilinear: pixels with more trace points than the 4 slots of the counting march, marched again */
   uint64_t big_steps;         /* steps that produced more trace points than the in-register step list (12): sorted in HBM */
-  uint64_t big_blend_pixels;  /* InterpolatingRectilinear: pixels whose four lattice corners hold more than 64 trace points */
+  uint64_t big_blend_pixels;  /* InterpolatingRectilinear: pixels whose four lattice corners hold more than 4 trace points together
+                                 (blended over a member arena in HBM; any number of points) */
   uint64_t terrain_lookups;   /* Rectilinear march: Terrain::get_elev evaluations actually performed.  A sample whose ray is
                                  above the highest post of the mosaic (+ 1 m) is above the terrain for certain, so its geodesic
                                  point and lookup are not evaluated — every ODE step, sign test and result stays the same;

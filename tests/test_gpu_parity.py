@@ -332,7 +332,7 @@ def _nested_cylinders(cfg, n, lat=46.53, lon=8.5, r0=4.0, dr=3.0, alpha=0.5):
 def test_more_trace_points_in_one_step_than_the_step_list(gpu_ctx, oracle_det, generator, w, h):
     """20 translucent cylinders nested inside one another 3.3 km ahead: the steps that cross them produce up to 41 trace points
     (step_result of the reference has no bound, utils.rs:213-282) against the 12 the device keeps in registers — those steps are
-    sorted in HBM (big_step_sort); an interpolating pixel's four lattice corners then hold > 64 points (k_interp_blend_big).
+    sorted in HBM (big_step_sort); an interpolating pixel's four lattice corners then hold well over a hundred points (k_interp_blend_big).
     Round 1 answered both with ATMRT_ERR_UNSUPPORTED."""
     from util import frame_stats
     cfg, tiles = synth.scene("S2", w, h, generator=generator, terrain_alpha=0.5, max_distance=20_000.0, tilt=3.0, fov=8.0)

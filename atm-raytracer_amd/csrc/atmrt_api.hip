@@ -53,6 +53,19 @@ struct DevBuf {
   }
   template <class T>
   T* as() const { return static_cast<T*>(ptr); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), cap(o.cap) { o.ptr = nullptr, o.cap = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { // std::swap of two buffers (run_interpolating keeps the lattice result that way)
+    if (this != &o) {
+      release();
+      ptr = o.ptr, cap = o.cap;
+      o.ptr = nullptr, o.cap = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); } // atmrt_ctx_destroy makes the context's device current before the context (and its buffers) goes
 };
 
 } // namespace
@@ -104,7 +117,7 @@ struct atmrt_ctx {
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
       d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev, d_step_prop,
-      d_blend_arena, d_object_rays;
+      d_blend_arena, d_object_rays, d_col_lo, d_col_hi, d_traced;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -294,8 +307,9 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
                     &c->d_plen, &c->d_npath, &c->d_hit_step, &c->d_hit_offset, &c->d_scan_tmp, &c->d_counters,
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
                     &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
-                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand, &c->d_path_seg, &c->d_dprev})
-    b->release();
+                    &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand, &c->d_path_seg, &c->d_dprev, &c->d_step_prop, &c->d_blend_arena,
+                    &c->d_object_rays})
+    b->release(); // (a buffer missing from this list is released by its destructor when the context is deleted below)
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_seg)
@@ -688,9 +702,15 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   if (f.p.generator != ATMRT_GEN_RECTILINEAR && f.n_objects > 0) {
     HIP_TRY(c, c->d_col_cand.reserve((size_t)f.wl * 64 * sizeof(int32_t)));
     HIP_TRY(c, c->d_col_ncand.reserve((size_t)f.wl * sizeof(int32_t)));
+    HIP_TRY(c, c->d_col_lo.reserve((size_t)f.wl * 64 * sizeof(double)));
+    HIP_TRY(c, c->d_col_hi.reserve((size_t)f.wl * 64 * sizeof(double)));
+    HIP_TRY(c, c->d_traced.reserve(npx));
   }
   ws->col_cand = c->d_col_cand.as<int32_t>();
   ws->col_ncand = c->d_col_ncand.as<int32_t>();
+  ws->col_lo = c->d_col_lo.as<double>();
+  ws->col_hi = c->d_col_hi.as<double>();
+  ws->traced = c->d_traced.as<uint8_t>();
   ws->pelev_t = c->d_pelev_t.as<double>();
   ws->plen_t = c->d_plen_t.as<double>();
   ws->npath = c->d_npath.as<int32_t>();

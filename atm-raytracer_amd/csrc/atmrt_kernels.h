@@ -122,6 +122,9 @@ struct Workspace {
   uint32_t* clist;        // object indices, ascending per sample
   int32_t* col_cand;      // [wl][64] objects that can be close to any sample of the column (ascending), and ...
   int32_t* col_ncand;     // ... their number; -1 = no list, test every object
+  double* col_lo;         // [wl][64] distances between which a sample of the column can be close to the candidate ...
+  double* col_hi;
+  uint8_t* traced;        // [h][wl] Fast with objects: 1 = the pixel can have a step with an object (k_fast_flag_rows)
   uint32_t* object_rays;  // Rectilinear, scenes with objects: pixels the lean march left to the general tracer
   double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)

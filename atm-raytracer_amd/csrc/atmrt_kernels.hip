@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
                                                         uint32_t* __restrict__ hit_count,
                                                         uint32_t* __restrict__ px_steps,
                                                         unsigned long long* __restrict__ counters, double* __restrict__ dprev_state,
-                                                        int i_begin, int i_end, int last_segment, uint32_t* __restrict__ slot_step) {
+                                                        int i_begin, int i_end, int last_segment, uint32_t* __restrict__ slot_step,
+                                                        uint32_t* __restrict__ slot_tag, const uint8_t* __restrict__ traced) {
+  // slot_tag != nullptr (scenes with objects, one launch over all samples): the slots are the general tracer's arena — entry
+  // p * RECT_SLOTS + j, tag ATMRT_COLOR_TERRAIN — and the pixels marked in `traced` are k_fast_trace's: their ray-steps are not
+  // counted here (whatever this scan stores for them is overwritten).
   // Samples i_begin .. i_end - 1 (the frame is scanned in the segments in which its ray paths are integrated, so that the scan
   // of one segment overlaps the integration of the next); between segments a pixel's state is the difference at its last
   // sample (dprev_state), its first hit (hit_step) and its count (hit_count).
@@ -178,8 +182,11 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
       if (MODE != 0 && hitbits && xok && y0 + r < f.h) { // rare: keep the first RECT_SLOTS crossings of the pixel for the list
         unsigned c = cnt0;
         const size_t pp = (size_t)(y0 + r) * wl + x;
-        for (unsigned hb = hitbits; hb && c < (unsigned)RECT_SLOTS; hb &= hb - 1, c++)
-          slot_step[(size_t)c * plane_px + pp] = (uint32_t)(i + __builtin_ctz(hb) - 1);
+        for (unsigned hb = hitbits; hb && c < (unsigned)RECT_SLOTS; hb &= hb - 1, c++) {
+          const size_t q = slot_tag ? pp * RECT_SLOTS + c : (size_t)c * plane_px + pp;
+          slot_step[q] = (uint32_t)(i + __builtin_ctz(hb) - 1);
+          if (slot_tag) slot_tag[q] = ATMRT_COLOR_TERRAIN;
+        }
       }
     }
     if (MODE == 0 && __all(nfound == RR)) {
@@ -198,8 +205,12 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
           const bool nh = hit && first[r] < 0;
           first[r] = nh ? i - 1 : first[r];
           if (MODE != 0 && hit) {
-            if (cnt[r] < (unsigned)RECT_SLOTS && xok && y0 + r < f.h)
-              slot_step[(size_t)cnt[r] * plane_px + (size_t)(y0 + r) * wl + x] = (uint32_t)(i - 1);
+            if (cnt[r] < (unsigned)RECT_SLOTS && xok && y0 + r < f.h) {
+              const size_t pp = (size_t)(y0 + r) * wl + x;
+              const size_t q = slot_tag ? pp * RECT_SLOTS + cnt[r] : (size_t)cnt[r] * plane_px + pp;
+              slot_step[q] = (uint32_t)(i - 1);
+              if (slot_tag) slot_tag[q] = ATMRT_COLOR_TERRAIN;
+            }
             cnt[r]++;
           }
           dprev[r] = d;
@@ -232,10 +243,15 @@ __global__ __launch_bounds__(256) void k_fast_intersect(Frame f, const double* _
       if (MODE == 0) {
         hit_count[p] = first[r] >= 0 ? 1u : 0u;
         st = first[r] >= 0 ? (unsigned)(first[r] + 1) : (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
+        if (slot_tag && first[r] >= 0) { // opaque terrain in a scene with objects: the first crossing is the pixel's only slot
+          slot_step[p * RECT_SLOTS] = (uint32_t)first[r];
+          slot_tag[p * RECT_SLOTS] = ATMRT_COLOR_TERRAIN;
+        }
       } else {
         hit_count[p] = cnt[r];
         st = (unsigned)(nrow[r] > 0 ? nrow[r] - 1 : 0);
       }
+      if (traced && traced[p]) st = 0;
       steps += st;
       if (px_steps) px_steps[p] = st;
     }
@@ -379,16 +395,67 @@ __global__ __launch_bounds__(256) void k_dense_from_packed(Frame f, const uint64
 constexpr int COL_CAND = 64;
 template <int CALC>
 __global__ __launch_bounds__(64) void k_column_candidates(Frame f, const DirCalc* __restrict__ colcalc, int32_t* __restrict__ ccand,
-                                                          int32_t* __restrict__ ncand, unsigned long long* __restrict__ counters) {
+                                                          int32_t* __restrict__ ncand, double* __restrict__ cand_lo,
+                                                          double* __restrict__ cand_hi, unsigned long long* __restrict__ counters) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= f.wl) return;
   int cand[COL_CAND];
+  double lo[COL_CAND], hi[COL_CAND]; // distances at which a sample of the column can be close to the candidate (k_fast_flag_rows)
   int n = 0;
-  const bool ok = ray_candidates<CALC, COL_CAND>(f, f.earth, colcalc[x], cand, n);
+  const bool ok = ray_candidates<CALC, COL_CAND>(f, f.earth, colcalc[x], cand, n, lo, hi);
   ncand[x] = ok ? n : -1;
   if (!ok && n == COL_CAND) atomicAdd(&counters[5], 1ull); // statistics only (atmrt_last_stats)
   if (ok)
-    for (int q = 0; q < n; q++) ccand[(size_t)x * COL_CAND + q] = cand[q];
+    for (int q = 0; q < n; q++) {
+      ccand[(size_t)x * COL_CAND + q] = cand[q];
+      cand_lo[(size_t)x * COL_CAND + q] = lo[q];
+      cand_hi[(size_t)x * COL_CAND + q] = hi[q];
+    }
+}
+
+// Fast generator with scene objects: which pixels can have a step that involves an object?  An object is tested at the sample pair
+// (i - 1, i) of column x only if it is close to one of the two samples — possible only while the sample's distance lies in the
+// candidate's interval [lo, hi] (candidate_interval: an exact superset) — and only by rows whose ray segment enters the object's height
+// band (object_out_of_band, the tracer's own test).  Every other pixel's result is its terrain crossings alone: the plain intersect
+// scan's.  One block per column and 256 rows: the column's candidates are wave-uniform, the ray elevations are read sample-major
+// (coalesced over rows).  A column without a candidate list (more than COL_CAND candidates, or an earth model without the
+// pre-filter) flags all its rows.
+__global__ __launch_bounds__(256) void k_fast_flag_rows(Frame f, const int32_t* __restrict__ ccand, const int32_t* __restrict__ ncand,
+                                                        const double* __restrict__ cand_lo, const double* __restrict__ cand_hi,
+                                                        const double* __restrict__ pelev_t, const int32_t* __restrict__ npath,
+                                                        uint8_t* __restrict__ flags) {
+  const int x = blockIdx.x;
+  const int y = blockIdx.y * blockDim.x + threadIdx.x;
+  if (y >= f.h) return;
+  const size_t p = (size_t)y * f.wl + x;
+  const int nc = ncand[x];
+  if (nc < 0) {
+    flags[p] = 1;
+    return;
+  }
+  int n = npath[y];
+  n = n < f.n_t ? n : f.n_t; // Iterator::zip, fast.rs:59-62
+  const size_t hh = (size_t)f.h;
+  const double step = f.p.simulation_step;
+  bool flag = false;
+  for (int q = 0; q < nc && !flag; q++) {
+    const ObjectDev& o = f.objects[ccand[(size_t)x * COL_CAND + q]];
+    const double lo = cand_lo[(size_t)x * COL_CAND + q], hi = cand_hi[(size_t)x * COL_CAND + q];
+    // samples whose distance xs[i] (= i * step up to rounding) can lie in [lo, hi], one more on either side; the pairs (i - 1, i)
+    // that contain one of them
+    double a = dm_floor(lo / step) - 1.0, b = dm_floor(hi / step) + 2.0;
+    if (!(a >= 1.0)) a = 1.0;           // also NaN / -inf
+    if (!(b <= (double)(n - 1))) b = (double)(n - 1);
+    const int i0 = (int)a, i1 = (int)b + 1 < n ? (int)b + 1 : n - 1;
+    for (int i = i0; i <= i1; i++) {
+      const double re0 = pelev_t[(size_t)(i - 1) * hh + y], re1 = pelev_t[(size_t)i * hh + y];
+      if (!((re0 < o.vlo && re1 < o.vlo) || (re0 > o.vhi && re1 > o.vhi))) {
+        flag = true;
+        break;
+      }
+    }
+  }
+  flags[p] = flag ? 1 : 0;
 }
 
 // TerrainData::from_lat_lon's proximity filter (utils.rs:74-80) for every (sample, column): count, then fill ascending lists
@@ -442,7 +509,10 @@ __global__ __launch_bounds__(256, ATMRT_FAST_TRACE_WAVES) void k_fast_trace(Fram
                                                     const uint64_t* __restrict__ hit_offset, PackedHits packed,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     uint32_t* __restrict__ px_steps,
-                                                    unsigned long long* __restrict__ counters, double* __restrict__ step_prop) {
+                                                    unsigned long long* __restrict__ counters, double* __restrict__ step_prop,
+                                                    const uint8_t* __restrict__ traced) {
+  // traced (counting pass): only the rows marked by k_fast_flag_rows are traced here — the others cannot meet an object and keep
+  // what the plain intersect scan found; a wavefront without a marked row leaves at once.
   // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
   // (packed / list_step / list_pixel then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its
   // place in the pixel-ordered list — for the pixels that did not fit their slots (hit_count > RECT_SLOTS); the others were
@@ -476,7 +546,9 @@ __global__ __launch_bounds__(256, ATMRT_FAST_TRACE_WAVES) void k_fast_trace(Fram
   const size_t p = (size_t)(row_ok ? y : 0) * f.wl + x;
   uint64_t k = (FILL && row_ok) ? hit_offset[p] : 0;
   unsigned count = 0, stp = 0;
-  bool active = n > 1 && (!FILL || hit_count[p] > (uint32_t)RECT_SLOTS);
+  const bool mine = FILL || !traced || (row_ok && traced[p] != 0);
+  bool active = n > 1 && mine && (!FILL || hit_count[p] > (uint32_t)RECT_SLOTS);
+  if (!__any(mine)) return;
   double te0 = kprof[x], re0 = n > 0 ? pelev_t[y] : 0.0;
   uint32_t c0 = kccount[x];
   constexpr int TCH = 8; // samples fetched ahead: every step's scalar loads would otherwise be a dependent round trip
@@ -605,12 +677,12 @@ __global__ __launch_bounds__(256, ATMRT_FAST_TRACE_WAVES) void k_fast_trace(Fram
     }
     i++;
   }
-  if (!FILL && row_ok) {
+  if (!FILL && row_ok && mine) {
     hit_count[p] = count;
     if (px_steps) px_steps[p] = stp;
   }
   if (!FILL) {
-    unsigned long long steps = wave_sum((unsigned long long)(row_ok ? stp : 0u));
+    unsigned long long steps = wave_sum((unsigned long long)(row_ok && mine ? stp : 0u));
     if (lane == 0 && steps) atomicAdd(&counters[0], steps);
   }
 }
@@ -1330,11 +1402,11 @@ static void launch_fast_intersect_segment(const Frame& f, Workspace& ws, const D
   if (f.opaque)
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 0>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
                        ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last,
-                       (uint32_t*)nullptr);
+                       (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint8_t*)nullptr);
   else
     hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 1>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath,
                        ws.hit_step, out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, i_begin, i_end, last,
-                       ws.slot_step);
+                       ws.slot_step, (uint32_t*)nullptr, (const uint8_t*)nullptr);
 }
 
 void launch_fast_intersect(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
@@ -1397,7 +1469,8 @@ void launch_scan_counts(const Frame& f, Workspace& ws, const uint32_t* hit_count
 void launch_close_count(const Frame& f, Workspace& ws, hipStream_t stream) {
   size_t n = (size_t)f.n_t * f.wl;
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_column_candidates<CALC>), dim3(cdiv(f.wl, 64)), dim3(64), 0, stream, f,
-                                                        ws.colcalc, ws.col_cand, ws.col_ncand, (unsigned long long*)ws.counters));
+                                                        ws.colcalc, ws.col_cand, ws.col_ncand, ws.col_lo, ws.col_hi,
+                                                        (unsigned long long*)ws.counters));
   hipLaunchKernelGGL((k_close_objects<false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, ws.plat, ws.plon, ws.col_cand,
                      ws.col_ncand, ws.ccount, (const uint64_t*)nullptr, (uint32_t*)nullptr);
   // total number of list entries -> counters[3]
@@ -1436,9 +1509,27 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
   }
   hipLaunchKernelGGL(k_paths_transpose, dim3(f.n_path_cap, cdiv(f.h, 256)), dim3(256), 0, stream, f, ws.pelev, ws.plen, ws.npath,
                      ws.pelev_t, ws.plen_t);
+  // Counting pass in three parts: (1) mark the pixels that can have a step with an object (k_fast_flag_rows); (2) the plain
+  // intersect scan over every pixel — terrain crossings only, at 6 instructions per ray-step — into the tracer's slot arena;
+  // (3) the general tracer (one column per wavefront, sequential over the samples) only over the marked rows, overwriting what
+  // the scan left for them.  Config 5: k_fast_trace<false> 14.2 -> ? ms.
+  hipLaunchKernelGGL(k_fast_flag_rows, dim3(f.wl, cdiv(f.h, 256)), dim3(256), 0, stream, f, ws.col_cand, ws.col_ncand, ws.col_lo, ws.col_hi,
+                     ws.pelev_t, ws.npath, ws.traced);
+  {
+    dim3 grid(cdiv(f.wl, 64), cdiv(f.h, 4 * FAST_RR));
+    if (f.p.terrain_alpha == 1.0)
+      hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 0>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath, ws.hit_step,
+                         out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, 1, f.n_path_cap, 1, ws.slot_step,
+                         ws.slot_packed.color_tag, (const uint8_t*)ws.traced);
+    else
+      hipLaunchKernelGGL((k_fast_intersect<FAST_RR, 1>), grid, dim3(256), 0, stream, f, ws.prof, ws.pelev, ws.npath, ws.hit_step,
+                         out.hit_count, ws.px_steps, (unsigned long long*)ws.counters, ws.dprev, 1, f.n_path_cap, 1, ws.slot_step,
+                         ws.slot_packed.color_tag, (const uint8_t*)ws.traced);
+  }
   hipLaunchKernelGGL((k_fast_trace<false>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                      ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, out.hit_count, (const uint64_t*)nullptr,
-                     ws.slot_packed, ws.slot_step, ws.slot_pixel, ws.px_steps, (unsigned long long*)ws.counters, (double*)nullptr);
+                     ws.slot_packed, ws.slot_step, ws.slot_pixel, ws.px_steps, (unsigned long long*)ws.counters, (double*)nullptr,
+                     (const uint8_t*)ws.traced);
 }
 
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
@@ -1451,7 +1542,8 @@ void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
                      (const uint32_t*)dense.hit_count, ws.hit_offset, ws.slot_step, ws.slot_packed, ws.list_step, ws.list_pixel, packed);
   hipLaunchKernelGGL((k_fast_trace<true>), dim3(cdiv(f.wl, 4), cdiv(f.h, 64)), dim3(256), 0, stream, f, ws.prof, ws.plat, ws.plon,
                      ws.ccount, ws.coffset, ws.clist, ws.pelev_t, ws.plen_t, ws.npath, dense.hit_count, ws.hit_offset, packed,
-                     ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters, ws.step_prop);
+                     ws.list_step, ws.list_pixel, (uint32_t*)nullptr, (unsigned long long*)ws.counters, ws.step_prop,
+                     (const uint8_t*)nullptr);
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_fast_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
                                                           stream, f, n_hits, ws.colcalc, ws.prof, ws.pelev, ws.plen,

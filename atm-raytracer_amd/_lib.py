@@ -39,7 +39,7 @@ def build(force=False):
     """Compile libatmrt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
-    subprocess.run(["make", "-s", "-j4", "-C", CSRC], check=True)
+    subprocess.run(["make", "-s", "-j8", "-C", CSRC], check=True)
     return LIB_PATH
 
 

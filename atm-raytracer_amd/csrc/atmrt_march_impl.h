@@ -1,7 +1,8 @@
 // atmrt_march_impl.h — Rectilinear generator on gfx950: the per-pixel march (RK4 ray + geodesic point + terrain gather per step),
-// its trace-point epilogue and the general tracer for scenes with objects.  Included by two translation units
-// (atmrt_march_linear.hip, atmrt_march_spline.hip) that instantiate the launchers for atmospheres without / with Spline
-// segments, so the heavy template variants (3 modes x 4 DirectionalCalc kinds x 2) compile in parallel.
+// its trace-point epilogue and the general tracer for scenes with objects.  Included by four translation units
+// (atmrt_march_{linear,spline}.hip, atmrt_trace_{linear,spline}.hip) that instantiate the launchers of the lean march / of the
+// general tracer for atmospheres without / with Spline segments, so the heavy template variants (4 + 2 modes x 4 DirectionalCalc
+// kinds x 2) compile in parallel.
 #pragma once
 // exp/log tables of detmath.h in LDS for this translation unit (6 KB per block): every kernel below calls stage_dm_tables() first.
 // The look-ups sit on the dependent chain of each n(h) evaluation; from LDS they cost ~1/3 of an L1 hit.
@@ -659,12 +660,14 @@ void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, co
   launch_dense_from_packed(f, ws, packed, dense, 0, stream);
 }
 
-// explicit instantiation of every launcher for one value of CUBIC
+// explicit instantiation of the launchers for one value of CUBIC, in two groups so that four translation units (march / trace x
+// linear / spline atmospheres) compile in parallel: the lean march (k_rect_march, all modes) and the general tracer (k_rect_trace)
 #define ATMRT_INSTANTIATE_MARCH(CUBIC)                                                                                        \
   template void launch_rect_march_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t, hipEvent_t);            \
   template void launch_multi_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,         \
                                            hipStream_t);                                                                      \
-  template void launch_rect_trace_count_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);                  \
+  template void launch_rect_trace_count_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
+#define ATMRT_INSTANTIATE_TRACE(CUBIC)                                                                                        \
   template void launch_rect_trace_objects_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t);      \
   template void launch_rect_trace_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,    \
                                                 hipStream_t);

@@ -10,6 +10,8 @@ extern template void launch_multi_fill_t<true>(const Frame&, Workspace&, uint64_
 extern template void launch_rect_trace_count_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
 extern template void launch_rect_trace_objects_t<true>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t);
 extern template void launch_rect_trace_fill_t<true>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
+extern template void launch_rect_trace_objects_t<false>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t); // atmrt_trace_linear.hip
+extern template void launch_rect_trace_fill_t<false>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
 
 void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
   if (f.atm_cubic) launch_rect_march_t<true>(f, ws, out, stream, ev_marched);

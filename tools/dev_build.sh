@@ -10,7 +10,7 @@ W=/tmp/dev/$NAME
 mkdir -p $W/atm-raytracer_amd/csrc $W/include
 cp $REPO/include/*.h $W/include/
 cp $REPO/atm-raytracer_amd/csrc/*.h $REPO/atm-raytracer_amd/csrc/*.hip $REPO/atm-raytracer_amd/csrc/Makefile $W/atm-raytracer_amd/csrc/
-make -s -j4 -C $W/atm-raytracer_amd/csrc DEV=1 EXTRA="$*"
+make -s -j8 -C $W/atm-raytracer_amd/csrc DEV=1 EXTRA="$*"
 mkdir -p $REPO/atm-raytracer_amd/csrc/dev/$NAME
 cp $W/atm-raytracer_amd/csrc/libatmrt.so $REPO/atm-raytracer_amd/csrc/dev/$NAME/libatmrt.so
 echo "built atm-raytracer_amd/csrc/dev/$NAME/libatmrt.so"

@@ -290,6 +290,24 @@ ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
   return 1.0 + dm_div(k_refr * pt, z);
 }
 
+// refr_from_tp at the three points of one ODE right-hand side (same layer, heights 1 cm apart): the same values as three calls; the
+// two division sites share their reciprocal refinement across the points (dm_div3)
+ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, double p0, double p1, double p2, double& n0, double& n1,
+                            double& n2) {
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
+  double pt0, pt1, pt2;
+  dm_div3(p0, t0, p1, t1, p2, t2, &pt0, &pt1, &pt2);
+  const double c0 = t0 - 273.15, c1 = t1 - 273.15, c2 = t2 - 273.15;
+  const double z0 = 1.0 - pt0 * (a0 + c0 * (a1 + c0 * a2)) + pt0 * pt0 * d;
+  const double z1 = 1.0 - pt1 * (a0 + c1 * (a1 + c1 * a2)) + pt1 * pt1 * d;
+  const double z2 = 1.0 - pt2 * (a0 + c2 * (a1 + c2 * a2)) + pt2 * pt2 * d;
+  double q0, q1, q2;
+  dm_div3(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, &q0, &q1, &q2);
+  n0 = 1.0 + q0;
+  n1 = 1.0 + q1;
+  n2 = 1.0 + q2;
+}
+
 // a knot interval of a Spline temperature function
 ATMRT_HD double refr_n_cubic_segment(double k_refr, double hb, double tb, double pb, double c1, double c2, double c3, double expo, double h) {
   double temp = seg_temperature(tb, c1, c2, c3, h - hb);
@@ -357,9 +375,7 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, doub
   double r0, r1, r2;
   if (lapse != 0.0) pow3(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
   else exp3(expo * (h0 - hb), expo * (h1 - hb), expo * (h2 - hb), r0, r1, r2);
-  n0 = refr_from_tp(k_refr, t0, pb * r0);
-  n1 = refr_from_tp(k_refr, t1, pb * r1);
-  n2 = refr_from_tp(k_refr, t2, pb * r2);
+  refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
 }
 
 // Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).

@@ -1353,6 +1353,11 @@ __global__ void k_math_probe(int op, size_t n, const double* __restrict__ a, con
       r1 = p1 + p2;
       break;
     }
+    case ATMRT_PROBE_DIV3: {
+      double q0;
+      dm_div3(x, y, x, y * 0.99999976158142090, x, y * 1.00000047683715820, &q0, &r0, &r1);
+      break;
+    }
     default: break;
   }
   out0[i] = r0;

@@ -88,6 +88,51 @@ DM_FN double dm_div(double a, double b) {
 DM_FN double dm_div(double a, double b) { return a / b; }
 #endif
 
+/* Three divisions a_i / b_i whose divisors are (expected to be) within 2^-20 of one another — the temperatures, and the
+ * compressibilities, of the three evaluations n(h), n(h - eps), n(h + eps) of one ODE right-hand side.  On the host: three IEEE
+ * divisions.  On gfx950: b_0's reciprocal is refined exactly as dm_div refines it and then SEEDS the two other reciprocals: with a
+ * seed error |1 - b_i r_0| <= 2^-20 two Newton steps leave 2^-80 before rounding, the same class of reciprocal dm_div's own two
+ * steps from v_rcp_f64 produce, and the quotient correction is dm_div's.  That saves the two quarter-rate v_rcp_f64 (the guard costs
+ * what the two instructions save).  The guard is a wave vote; lanes that fail it (or hold NaN) send the whole wavefront through
+ * dm_div.  Same operand range as dm_div.  tests/test_gpu_detmath.py checks the sequence against IEEE division like dm_div. */
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN void dm_div3(double a0, double b0, double a1, double b1, double a2, double b2, double* q0, double* q1, double* q2) {
+  double r = __builtin_amdgcn_rcp(b0);
+  double e = __builtin_fma(-b0, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b0, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = a0 * r;
+  e = __builtin_fma(-b0, q, a0);
+  *q0 = __builtin_fma(e, r, q);
+  double e1 = __builtin_fma(-b1, r, 1.0), e2 = __builtin_fma(-b2, r, 1.0);
+  double m = __builtin_fmax(__builtin_fabs(e1), __builtin_fabs(e2));
+  if (__all(m <= 9.5367431640625e-07)) { /* 2^-20; false for NaN */
+    double r1 = __builtin_fma(r, e1, r);
+    e1 = __builtin_fma(-b1, r1, 1.0);
+    r1 = __builtin_fma(r1, e1, r1);
+    q = a1 * r1;
+    e1 = __builtin_fma(-b1, q, a1);
+    *q1 = __builtin_fma(e1, r1, q);
+    double r2 = __builtin_fma(r, e2, r);
+    e2 = __builtin_fma(-b2, r2, 1.0);
+    r2 = __builtin_fma(r2, e2, r2);
+    q = a2 * r2;
+    e2 = __builtin_fma(-b2, q, a2);
+    *q2 = __builtin_fma(e2, r2, q);
+  } else {
+    *q1 = dm_div(a1, b1);
+    *q2 = dm_div(a2, b2);
+  }
+}
+#else
+DM_FN void dm_div3(double a0, double b0, double a1, double b1, double a2, double b2, double* q0, double* q1, double* q2) {
+  *q0 = a0 / b0;
+  *q1 = a1 / b1;
+  *q2 = a2 / b2;
+}
+#endif
+
 /* a / b given y = RN(1/b) (a correctly rounded reciprocal, e.g. tabulated on the host): two residual corrections.  After the
  * first, q1 is a faithful quotient; with y correctly rounded the second then yields RN(a/b) (Markstein's theorem), for operands
  * in the range described at dm_div.  5 instructions.  dm_div_r_seq is the sequence itself (tests/test_detmath.py checks it

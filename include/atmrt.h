@@ -358,8 +358,10 @@ typedef enum atmrt_math_probe_op {
   ATMRT_PROBE_IEEE_SQRT = 10,   /* the compiler's sqrt(a) */
   ATMRT_PROBE_ATAN = 11,
   ATMRT_PROBE_TAN = 12,
-  ATMRT_PROBE_POW3 = 13         /* out0 = dm_pow(a, b) through the three-point form of the stepping kernels; out1 = sum of
+  ATMRT_PROBE_POW3 = 13,        /* out0 = dm_pow(a, b) through the three-point form of the stepping kernels; out1 = sum of
                                    the other two points (a * 0.99999981, a * 1.00000019) */
+  ATMRT_PROBE_DIV3 = 14         /* dm_div3: out0 = a / (b (1 - 2^-22)), out1 = a / (b (1 + 2^-21)), both with their reciprocal seeded
+                                   from b's; the centre quotient a / b is ATMRT_PROBE_DIV's */
 } atmrt_math_probe_op;
 int atmrt_math_probe(atmrt_ctx* ctx, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1);
 

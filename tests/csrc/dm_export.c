@@ -17,3 +17,9 @@ void t_pow3(const double* a, const double* b, double* y0, double* y1, size_t n) 
     y1[i] = dm_pow(a[i] * 0.99999981, b[i]) + dm_pow(a[i] * 1.00000019, b[i]);
   }
 }
+void t_div3(const double* a, const double* b, double* y0, double* y1, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    double q0;
+    dm_div3(a[i], b[i], a[i], b[i] * 0.99999976158142090, a[i], b[i] * 1.00000047683715820, &q0, &y0[i], &y1[i]);
+  }
+}

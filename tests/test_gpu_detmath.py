@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 N = 10_000_000
 OPS = dict(DIV=0, DIV_R=1, SQRT_INRANGE=2, EXP=3, LOG=4, POW=5, SINCOS=6, ASIN=7, ATAN2=8, IEEE_DIV=9, IEEE_SQRT=10, ATAN=11,
-           TAN=12, POW3=13)
+           TAN=12, POW3=13, DIV3=14)
 
 
 @pytest.fixture(scope="module")
@@ -106,6 +106,37 @@ def test_dm_div_r_is_ieee_division_in_range(gpu_ctx, host):
     same(gpu(gpu_ctx, "DIV_R", t, tb), t / tb, "T / T_b")
     dn = rng.uniform(-1e-6, 1e-6, N) * 10.0 ** rng.uniform(-6, 0, N)
     same(gpu(gpu_ctx, "DIV_R", dn, np.full(N, 0.02)), dn / 0.02, "dn / (2 eps)")
+
+
+def test_dm_div3_seeded_reciprocals_give_ieee_quotients(gpu_ctx, host):
+    """dm_div3 (the two division sites of the three n(h) evaluations of one ODE right-hand side): the outer divisors' reciprocals
+    are refined from the centre divisor's instead of from v_rcp_f64; the quotients must be IEEE's all the same."""
+    rng = np.random.default_rng(16)
+    a, b = in_range_pairs(rng, N, lim=480)
+    with np.errstate(all="ignore"):
+        q1, q2 = gpu(gpu_ctx, "DIV3", a, b, two=True)
+        same(q1, a / (b * 0.99999976158142090), "dm_div3 outer divisor below")
+        same(q2, a / (b * 1.00000047683715820), "dm_div3 outer divisor above")
+    h1, h2 = cpu(host, "div3", a, b, outs=2)
+    same(q1, h1, "dm_div3 vs host")
+    same(q2, h2, "dm_div3 vs host")
+    # the call sites' operands: pressures over temperatures, and k (p/T) over Z
+    p = rng.uniform(100.0, 115000.0, N)
+    t = rng.uniform(150.0, 330.0, N)
+    q1, q2 = gpu(gpu_ctx, "DIV3", p, t, two=True)
+    same(q1, p / (t * 0.99999976158142090), "p / T")
+    same(q2, p / (t * 1.00000047683715820), "p / T")
+    kz = rng.uniform(1e-7, 3e-4, N)
+    z = 1.0 - rng.uniform(0.0, 1.2e-3, N)
+    q1, q2 = gpu(gpu_ctx, "DIV3", kz, z, two=True)
+    same(q1, kz / (z * 0.99999976158142090), "k pt / Z")
+    same(q2, kz / (z * 1.00000047683715820), "k pt / Z")
+    # wavefronts in which some lanes hold NaN / zero divisors: the vote fails and everything goes through dm_div
+    b2 = np.where(rng.uniform(size=N) < 0.01, rng.choice([np.nan, np.inf], N), t)
+    with np.errstate(all="ignore"):
+        q1, q2 = gpu(gpu_ctx, "DIV3", p, b2, two=True)
+        ok = np.isfinite(b2)
+        same(q1[ok], (p / (b2 * 0.99999976158142090))[ok], "dm_div3 beside NaN lanes")
 
 
 def test_dm_sqrt_inrange_is_ieee_sqrt_in_range(gpu_ctx, host):

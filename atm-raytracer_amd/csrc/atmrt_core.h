@@ -332,7 +332,7 @@ ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, dou
 ATMRT_HD void pow3(double x0, double x1, double x2, double y, double& r0, double& r1, double& r2) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (__all(dm_log_in_main_range(x0) && dm_log_in_main_range(x1) && dm_log_in_main_range(x2))) {
-    const double e0 = y * dm_log_core(x0, 0), e1 = y * dm_log_core(x1, 0), e2 = y * dm_log_core(x2, 0);
+    const double e0 = y * dm_log_core_pow(x0), e1 = y * dm_log_core_pow(x1), e2 = y * dm_log_core_pow(x2);
     if (__all(dm_exp_in_main_range(e0) && dm_exp_in_main_range(e1) && dm_exp_in_main_range(e2))) {
       r0 = dm_exp_main(e0);
       r1 = dm_exp_main(e1);

@@ -471,6 +471,29 @@ DM_FN double dm_log_core(double x, int32_t k0) {
   p = DM_FMA(r, p, -0.5);
   return DM_FMA(r2, p, l) + h;
 }
+/* The same reduction and polynomial without the double-double accumulation, for pow(x, y) = exp(y log x): w = k ln2_hi + logc_hi is
+ * exact, r + r^2 p(r) and the low words are tiny beside it (or, in the interval around 1 where w = 0, ARE the result), so the only
+ * rounding of weight is the final addition: <= 1.1 ulp instead of 0.74, three instructions fewer — and pow's own error is dominated by
+ * the rounding of y log x anyway.  Used by dm_pow (and by the stepping kernels' three-point form) only; dm_log keeps the accurate core. */
+DM_FN double dm_log_core_pow(double x) {
+  uint64_t ix = dm_bits(x);
+  uint32_t hi = (uint32_t)(ix >> 32);
+  int32_t u = (int32_t)(((hi + 0x1000u) & 0xffffe000u) - 0x3fe6a000u);
+  int32_t k = u >> 20;
+  const double* t = DM_LOG_ROW((u >> 13) & 127);
+  double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)(hi - ((uint32_t)u & 0xfff00000u)) << 32));
+  double r = DM_FMA(z, t[0], -1.0);
+  double kd = (double)k;
+  double w = DM_FMA(kd, DM_LN2_HI, t[1]);
+  double lo = DM_FMA(kd, DM_LN2_LO, t[2]);
+  double r2 = r * r, p;
+  p = DM_FMA(r, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  p = DM_FMA(r, p, 0.2);
+  p = DM_FMA(r, p, -0.25);
+  p = DM_FMA(r, p, 3.33333333333333333e-01);
+  p = DM_FMA(r, p, -0.5);
+  return w + (DM_FMA(r2, p, r) + lo);
+}
 DM_FN double dm_log_slow(double x) { /* nan, negative, zero, inf, subnormal */
   if (dm_isnan(x)) return x + x;
   if (x < 0.0) return (x - x) / (x - x);
@@ -489,6 +512,6 @@ DM_FN double dm_log(double x) {
 }
 
 /* x > 0 only (barometric formula: base = T/T_b in (0, 2)).  <= 3 ulp for |y ln x| <= 4. */
-DM_FN double dm_pow(double x, double y) { return dm_exp(y * dm_log(x)); }
+DM_FN double dm_pow(double x, double y) { return dm_exp(y * (dm_log_in_main_range(x) ? dm_log_core_pow(x) : dm_log_slow(x))); }
 
 #endif /* ATMRT_DETMATH_H */

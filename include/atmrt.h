@@ -34,7 +34,8 @@ typedef enum atmrt_status {
   ATMRT_ERR_IO = -4,               /* terrain directory or file unreadable (terrain/mod.rs:70-71) */
   ATMRT_ERR_FORMAT = -5,           /* a file in the terrain directory is not a DTED tile (terrain/mod.rs:113-118) */
   ATMRT_ERR_STATE = -6,            /* call order violated (e.g. generate before set_params) */
-  ATMRT_ERR_UNSUPPORTED = -7       /* a fixed capacity of the device path was exceeded (message says which) */
+  ATMRT_ERR_UNSUPPORTED = -7       /* reserved; not returned since ABI 3: the fixed capacities of ABI 2 (12 trace points per step, 64
+                                      corner points per interpolating pixel) now have unbounded routes */
 } atmrt_status;
 
 /* EarthModel, src/utils/earth_model/mod.rs:19-28 (same order as the Rust enum). */

@@ -36,7 +36,7 @@ def _shard(name, generator, c0, w=2, **kw):
     return cfg
 
 
-@pytest.mark.parametrize("generator", ["Rectilinear", "Fast"])
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast", "InterpolatingRectilinear"])
 def test_config3_4096x2048_step_50m(gpu_ctx, oracle_det, s3_tiles, generator):
     """BASELINE config 3: 4096x2048, 3x3 tiles, step 50 m, 200 km (N_t = 4000 samples per ray)."""
     cfg = synth.scene("S3", generator=generator)[0]
@@ -49,7 +49,7 @@ def test_config3_4096x2048_step_50m(gpu_ctx, oracle_det, s3_tiles, generator):
     assert n > 1000
 
 
-@pytest.mark.parametrize("generator", ["Rectilinear", "Fast"])
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast", "InterpolatingRectilinear"])
 def test_config4_8192x4096_5x5_tiles_and_one_of_eight_shards(gpu_ctx, oracle_det, s4_tiles, generator):
     """BASELINE config 4: 8192x4096 over 5x5 tiles — the whole frame on one GPU, and the shard rank 3 of 8 would compute
     (columns 3072..4095), both against the oracle's columns; the shard must also equal the full frame's columns."""
@@ -128,7 +128,7 @@ def test_config5_candidate_lists_overflow(gpu_ctx, oracle_det, s3_tiles):
             assert_columns_match(full, run_oracle(oracle_det, shard, s3_tiles, rows=rows), c0, rows=rows)
 
 
-@pytest.mark.parametrize("generator", ["Rectilinear", "Fast"])
+@pytest.mark.parametrize("generator", ["Rectilinear", "Fast", "InterpolatingRectilinear"])
 def test_headline_on_the_benched_level2_mosaic(gpu_ctx, oracle_det, s3_tiles_level2, generator):
     """What bench.py runs: the headline frame over 9 level-2 tiles (3601 x 3601 posts each, 233 MB mosaic)."""
     assert all(t.shape == (3601, 3601) for t in s3_tiles_level2.values())

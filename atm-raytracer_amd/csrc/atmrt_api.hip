@@ -526,6 +526,9 @@ extern "C" int atmrt_set_params(atmrt_ctx* c, const atmrt_params_t* p) {
   if (p->simulation_step != c->params.simulation_step || p->frame.max_distance != c->params.frame.max_distance ||
       !c->have_params)
     c->xs_dirty = true;
+  // distances handed to SphericalCalc are sums of steps and interpolation points inside a step: 0 or >= ~1e-17 step
+  if (e.calc_radius >= 1.0e-30 && e.calc_radius <= 1.0e30 && p->simulation_step >= 1.0e-10 && p->frame.max_distance <= 1.0e30)
+    e.flat_dirs |= EARTH_FAST_DIV;
   c->params = *p;
   c->earth = e;
   c->have_params = true;
@@ -582,6 +585,7 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   if (rc) return rc;
   const atmrt_params_t& p = c->params;
   if (atm_compile(c->atm_def, p.wavelength, c->atm)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere");
+  atm_certify(c->atm, c->earth.spherical != 0, c->earth.shape_radius, p.simulation_step);
   pinhole_init(p, c->pinhole);
   if (c->xs_dirty) {
     // distance table by repeated addition, exactly like `distance += step` (utils.rs:191-196) and the

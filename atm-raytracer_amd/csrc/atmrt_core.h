@@ -60,6 +60,12 @@ struct AtmTable {
   int32_t cubic[ATMRT_MAX_ATM_SEGMENTS];
   double k_refr;                        // (n - 1) = k_refr * (p/T) / Z
   double rtb[ATMRT_MAX_ATM_SEGMENTS];   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
+  // atm_certify: the part [safe_lo, safe_hi) of segment k over which T, p, p/T, Z and n are PROVEN to stay inside the operand range of
+  // the GPU's division / square-root shortcuts (detmath.h); empty (lo = +inf) when nothing can be proven.  An evaluation outside it
+  // takes the IEEE operations, so a pathological atmosphere (a spline that overshoots to 30 K, a pressure of 1e308 Pa) is slower but
+  // still bit-identical to the host.  [alt_lo, alt_hi]: the altitudes at which a path-length step may use the shortcuts.
+  double safe_lo[ATMRT_MAX_ATM_SEGMENTS], safe_hi[ATMRT_MAX_ATM_SEGMENTS];
+  double alt_lo, alt_hi;
 };
 
 ATMRT_HD int atm_layer(const AtmTable& a, double h) {
@@ -275,19 +281,158 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
   return 0;
 }
 
+// ---- the certificate behind the GPU's shortcut divisions (AtmTable::safe_lo / safe_hi / alt_lo / alt_hi) ----------------------
+// Can every evaluation of n(h), h in [lo, hi] inside segment k, keep its operands where dm_div / dm_div3 / dm_div_r return the
+// IEEE quotient?  Sufficient conditions, with margins of hundreds of binades to the real limits (|exponent| < 500):
+//   1 K <= T <= 1e5 K on the interval (and at the quadrature nodes of a cubic segment, which lie between hb and h);
+//   1e-250 Pa <= p <= 1e250 Pa  (p is monotone in h while T > 0: the end points bound it; a cubic segment: p <= pb, and the
+//   quadrature of 1/T is at most (h - hb) / Tmin);
+//   |Z - 1| <= (p/T) |a0 + a1 t + a2 t^2| + (p/T)^2 d <= 1/2, bounded from max p / min T and max |t|;
+//   n - 1 = k_refr (p/T) / Z <= 2^8.
+// The predicate is monotone: a sub-interval of an interval that passes passes.
+inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double hi) {
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
+  const double tb = t.tb[k], pb = t.pb[k];
+  if (!(tb >= 1.0 && tb <= 1.0e5) || !(pb >= 1.0e-250 && pb <= 1.0e250)) return false;
+  double tmin, tmax, pmin, pmax;
+  if (t.cubic[k]) {
+    const double c1 = t.lapse[k], c2 = t.c2[k], c3 = t.c3[k];
+    const double d1 = hi - t.hb[k]; // T over [hb, hi]: the evaluation points and the quadrature nodes
+    if (!(d1 >= 0.0) || !(lo >= t.hb[k])) return false;
+    tmin = tmax = tb;
+    double cand[3] = {d1, -1.0, -1.0};
+    if (c3 != 0.0) {
+      const double disc = c2 * c2 - 3.0 * c3 * c1;
+      if (disc >= 0.0) {
+        const double r = dm_sqrt(disc);
+        cand[1] = (-c2 + r) / (3.0 * c3);
+        cand[2] = (-c2 - r) / (3.0 * c3);
+      }
+    } else if (c2 != 0.0) {
+      cand[1] = -c1 / (2.0 * c2);
+    }
+    for (int i = 0; i < 3; i++) {
+      if (!(cand[i] >= 0.0 && cand[i] <= d1)) continue;
+      const double v = seg_temperature(tb, c1, c2, c3, cand[i]);
+      tmin = v < tmin ? v : tmin;
+      tmax = v > tmax ? v : tmax;
+    }
+    // the stationary points are located in floating point: allow for it
+    tmin -= 1.0e-6 * (dm_fabs(tmin) + dm_fabs(tmax)) + 1.0e-6;
+    tmax += 1.0e-6 * (dm_fabs(tmin) + dm_fabs(tmax)) + 1.0e-6;
+    if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
+    pmax = pb;
+    pmin = pb * dm_exp(t.expo[k] * d1 / tmin); // expo < 0
+  } else {
+    if (t.lapse[k] != 0.0 && !(dm_fabs(t.expo[k]) <= 1.0e6)) return false; // a lapse rate below 4e-8 K/m: the exponent of pow runs away
+    const double t0 = atm_seg_temperature(t, k, lo), t1 = atm_seg_temperature(t, k, hi);
+    tmin = t0 < t1 ? t0 : t1;
+    tmax = t0 < t1 ? t1 : t0;
+    if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
+    const double p0 = pb * atm_pressure_ratio(t, k, lo), p1 = pb * atm_pressure_ratio(t, k, hi);
+    pmin = p0 < p1 ? p0 : p1;
+    pmax = p0 < p1 ? p1 : p0;
+  }
+  if (!(pmin >= 1.0e-250 && pmax <= 1.0e250)) return false;
+  const double ptmax = pmax / tmin * 1.000001;
+  const double tm0 = dm_fabs(tmin - 273.15), tm1 = dm_fabs(tmax - 273.15), tm = tm0 > tm1 ? tm0 : tm1;
+  const double amax = a0 + tm * (dm_fabs(a1) + tm * a2);
+  if (!(ptmax * amax + ptmax * ptmax * d <= 0.5)) return false;
+  return t.k_refr * ptmax * 2.0 <= 256.0;
+}
+
+// Fills safe_lo / safe_hi / alt_lo / alt_hi: for every segment an interval around an anchor altitude (sea level, the
+// segment's base, its middle or an end) that atm_interval_certified accepts, inside the global band of altitudes [alt_lo, alt_hi] =
+// [max(-100 km, 1 km - radius), 10 000 km].  Nothing is certified for a step outside 1 mm .. 1e8 m, a radius outside 1 km .. 1e12 m
+// or a refractivity constant outside 1e-12 .. 1e-3 (a wavelength on a resonance of the dispersion formula).
+inline void atm_certify(AtmTable& t, bool spherical, double radius, double step) {
+  for (int k = 0; k < ATMRT_MAX_ATM_SEGMENTS; k++) {
+    t.safe_lo[k] = dm_inf();
+    t.safe_hi[k] = -dm_inf();
+  }
+  t.alt_lo = dm_inf();
+  t.alt_hi = -dm_inf();
+  if (!(step >= 1.0e-3 && step <= 1.0e8)) return;
+  if (spherical && !(radius >= 1.0e3 && radius <= 1.0e12)) return;
+  if (!(t.k_refr >= 1.0e-12 && t.k_refr <= 1.0e-3)) return;
+  double gl = -1.0e5;
+  const double gh = 1.0e7;
+  if (spherical && 1000.0 - radius > gl) gl = 1000.0 - radius;
+  t.alt_lo = gl;
+  t.alt_hi = gh;
+  for (int k = 0; k < t.n; k++) {
+    const double L = k > 0 && t.from[k] > gl ? t.from[k] : gl;
+    const double H = k + 1 < t.n && t.from[k + 1] < gh ? t.from[k + 1] : gh;
+    if (!(L < H)) continue;
+    double lo = L, hi = H;
+    if (!atm_interval_certified(t, k, lo, hi)) {
+      const double cands[5] = {0.0, t.hb[k], 0.5 * (L + H), L, H};
+      double a = 0.0;
+      bool have = false;
+      for (int i = 0; i < 5 && !have; i++) {
+        a = cands[i] < L ? L : (cands[i] > H ? H : cands[i]);
+        have = atm_interval_certified(t, k, a, a);
+      }
+      if (!have) continue;
+      // upwards first (that is where rays spend their time), then downwards with the upper end fixed: certified jointly
+      if (atm_interval_certified(t, k, a, H)) {
+        hi = H;
+      } else {
+        double good = a, bad = H;
+        for (int it = 0; it < 60; it++) {
+          const double mid = 0.5 * (good + bad);
+          if (atm_interval_certified(t, k, a, mid)) good = mid;
+          else bad = mid;
+        }
+        hi = good;
+      }
+      if (atm_interval_certified(t, k, L, hi)) {
+        lo = L;
+      } else {
+        double good = a, bad = L;
+        for (int it = 0; it < 60; it++) {
+          const double mid = 0.5 * (good + bad);
+          if (atm_interval_certified(t, k, mid, hi)) good = mid;
+          else bad = mid;
+        }
+        lo = good;
+      }
+      if (!atm_interval_certified(t, k, lo, hi) || !(lo < hi)) continue;
+    }
+    t.safe_lo[k] = lo;
+    t.safe_hi[k] = hi;
+  }
+}
+
 ATMRT_HD double atm_temperature(const AtmTable& a, double h) { return atm_seg_temperature(a, atm_layer(a, h), h); }
 ATMRT_HD double atm_pressure(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
   return a.pb[k] * atm_pressure_ratio(a, k, h);
 }
 
+// FAST selects the GPU's shortcut sequences (dm_div ...: the IEEE result for in-range operands only) and is passed as true only for
+// evaluations inside a certified altitude interval (AtmTable::safe_lo); FAST = false is the IEEE operation.  Same value on the host.
+template <bool FAST>
+ATMRT_HD double div_sel(double a, double b) {
+  return FAST ? dm_div(a, b) : a / b;
+}
+// a wave vote on the GPU (the branch it guards then is uniform), the predicate itself on the host
+ATMRT_HD bool wave_all(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __all(p);
+#else
+  return p;
+#endif
+}
+
 // Ciddor's (n - 1) = K (p/T) / Z for dry air
+template <bool FAST = false>
 ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   double t = temp - 273.15;
-  double pt = dm_div(p, temp);
+  double pt = div_sel<FAST>(p, temp);
   double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
-  return 1.0 + dm_div(k_refr * pt, z);
+  return 1.0 + div_sel<FAST>(k_refr * pt, z);
 }
 
 // refr_from_tp at the three points of one ODE right-hand side (same layer, heights 1 cm apart): the same values as three calls; the
@@ -309,22 +454,23 @@ ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, doub
 }
 
 // a knot interval of a Spline temperature function
+template <bool FAST = false>
 ATMRT_HD double refr_n_cubic_segment(double k_refr, double hb, double tb, double pb, double c1, double c2, double c3, double expo, double h) {
   double temp = seg_temperature(tb, c1, c2, c3, h - hb);
   double p = pb * dm_exp(expo * seg_inv_t_integral(tb, c1, c2, c3, h - hb));
-  return refr_from_tp(k_refr, temp, p);
+  return refr_from_tp<FAST>(k_refr, temp, p);
 }
 
 // Environment::n(h) for a point known to lie in the segment with these parameters.  CUBIC = false instantiates only the
 // closed-form path of Linear functions: the stepping kernels are compiled in both variants and the host picks by
 // whether the atmosphere has Spline segments (inlining the quadrature path twelve times per RK4 step costs 9 % on US-76).
-template <bool CUBIC = true>
+template <bool CUBIC = true, bool FAST = false>
 ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3,
                              double expo, double h) {
-  if (CUBIC && cubic) return refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h);
+  if (CUBIC && cubic) return refr_n_cubic_segment<FAST>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h);
   double temp = tb + lapse * (h - hb);
-  double ratio = lapse != 0.0 ? dm_pow(dm_div(temp, tb), expo) : dm_exp(expo * (h - hb));
-  return refr_from_tp(k_refr, temp, pb * ratio);
+  double ratio = lapse != 0.0 ? dm_pow(div_sel<FAST>(temp, tb), expo) : dm_exp(expo * (h - hb));
+  return refr_from_tp<FAST>(k_refr, temp, pb * ratio);
 }
 
 // refr_n_layer at three points of one layer.  Same values as three calls; on the GPU the range guards of log and exp are
@@ -366,9 +512,9 @@ template <bool CUBIC = true>
 ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, double rtb, double pb, double lapse, double c2, double c3,
                             double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2) {
   if (CUBIC && cubic) {
-    n0 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
-    n1 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
-    n2 = refr_n_cubic_segment(k_refr, hb, tb, pb, lapse, c2, c3, expo, h2);
+    n0 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
+    n1 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
+    n2 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h2);
     return;
   }
   const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
@@ -378,7 +524,8 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, doub
   refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
 }
 
-// Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).
+// Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).  IEEE operations throughout: the
+// generic evaluation, valid for any atmosphere at any altitude.
 ATMRT_HD double refr_n(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
   return refr_n_layer(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
@@ -390,37 +537,37 @@ ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   return (n2 - n1) / (2.0 * eps);
 }
 
-// Same values as refr_n, organised for the wavefront: `hint` is the layer of the previous evaluation.  When every
-// active lane is still inside that layer (the normal case: rays stay below 11 km) the layer search is two compares and
-// the layer parameters are wave-uniform scalars; otherwise the lane falls back to the full search and a gather.
+// One evaluation of n(h) with the shortcut divisions, organised for the wavefront of the path kernel (atmrt_paths.hip): `hint` is the
+// layer of the lane's previous evaluation.  When every active lane is inside the certified part of the first lane's layer (rays
+// below 11 km in a physical atmosphere) the layer search is two compares and the layer parameters are wave-uniform scalars;
+// otherwise every lane makes the full search and gathers its own parameters (eight rays of different elevations share a wavefront
+// there: the normal case above 11 km).  `certified` (per lane): the point lies in the certified part of its layer, i.e. the value is
+// refr_n's.  If it is false the value is NOT to be used — the caller verifies the flags of a whole step with one vote and repeats
+// the step with IEEE operations when one is false.  GPU only.
+#if defined(__HIPCC__)
 template <bool CUBIC>
-ATMRT_HD double refr_n_hint(const AtmTable& a, double h, int& hint) {
-#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, double h, int& hint, bool& certified) {
   const int ku = __builtin_amdgcn_readfirstlane(hint);
-  const bool ok = (ku == 0 || h >= a.from[ku]) && (ku == a.n - 1 || h < a.from[ku + 1]);
-  if (__all(ok))
-    return refr_n_layer<CUBIC>(a.k_refr, a.cubic[ku], a.hb[ku], a.tb[ku], a.pb[ku], a.lapse[ku], a.c2[ku], a.c3[ku], a.expo[ku], h);
-  const int k = ok ? ku : atm_layer(a, h);
+  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
+  const ConstTable ka = (ConstTable)(uintptr_t)&a;
+  if (__all(h >= ka->safe_lo[ku] && h < ka->safe_hi[ku])) {
+    certified = true;
+    return refr_n_layer<CUBIC, true>(ka->k_refr, ka->cubic[ku], ka->hb[ku], ka->tb[ku], ka->pb[ku], ka->lapse[ku], ka->c2[ku], ka->c3[ku],
+                                     ka->expo[ku], h);
+  }
+  const int k = atm_layer(a, h);
   hint = k;
-  return refr_n_layer<CUBIC>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
-#else
-  (void)hint;
-  return refr_n(a, h);
+  certified = h >= a.safe_lo[k] && h < a.safe_hi[k];
+  return refr_n_layer<CUBIC, true>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+}
 #endif
-}
-template <bool CUBIC>
-ATMRT_HD double refr_dn_hint(const AtmTable& a, double h, int& hint) {
-  const double eps = 0.01;
-  double n1 = refr_n_hint<CUBIC>(a, h - eps, hint);
-  double n2 = refr_n_hint<CUBIC>(a, h + eps, hint);
-  return dm_div(n2 - n1, 2.0 * eps);
-}
 
 // n(h) and dn/dh(h) of one ODE right-hand side: the three evaluations at h, h - eps and h + eps.  When all three points of
-// every active lane lie in the hinted layer (they are 1 cm apart), one check and one set of scalar layer parameters serve the
-// three evaluations and their instruction streams interleave (the table look-ups of exp/log are the long latencies here).
+// every active lane lie in the certified part of the hinted layer (they are 1 cm apart), one check and one set of scalar layer
+// parameters serve the three evaluations and their instruction streams interleave (the table look-ups of exp/log are the long
+// latencies here).  Returns whether that path was taken (wave-uniform): n then is in [1, 2^9] and the caller may go on with the shortcuts.
 template <bool CUBIC>
-ATMRT_HD void refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, double& dn) {
+ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, double& dn) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double eps = 0.01;
   const int ku = __builtin_amdgcn_readfirstlane(hint);
@@ -428,19 +575,33 @@ ATMRT_HD void refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
   typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
   const ConstTable ka = (ConstTable)(uintptr_t)&a;
-  const bool ok = (ku == 0 || h1 >= ka->from[ku]) && (ku == ka->n - 1 || h2 < ka->from[ku + 1]);
-  if (__all(ok)) {
+  if (__all(h1 >= ka->safe_lo[ku] && h2 < ka->safe_hi[ku])) {
     const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], rtb = ka->rtb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
                  c3 = ka->c3[ku], expo = ka->expo[ku];
     const int cubic = ka->cubic[ku];
     double n1, n2;
     refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
     dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
-    return;
+    return true;
   }
+  // generic: per-lane layer search, IEEE operations.  The hint follows the lane, so that the fast path resumes once the
+  // wavefront is back inside one certified interval.
+  {
+    const int k = atm_layer(a, h);
+    hint = k;
+    n = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+    const int k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
+    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k1], a.hb[k1], a.tb[k1], a.pb[k1], a.lapse[k1], a.c2[k1], a.c3[k1], a.expo[k1], h1);
+    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k2], a.hb[k2], a.tb[k2], a.pb[k2], a.lapse[k2], a.c2[k2], a.c3[k2], a.expo[k2], h2);
+    dn = (n2 - n1) / (2.0 * eps);
+    return false;
+  }
+#else
+  (void)hint;
+  n = refr_n(a, h);
+  dn = refr_dn(a, h);
+  return false;
 #endif
-  n = refr_n_hint<CUBIC>(a, h, hint);
-  dn = refr_dn_hint<CUBIC>(a, h, hint);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,7 +616,7 @@ constexpr double WGS84_B = 6356752.314245;            // :16
 // EarthModel resolved once on the host into the four behaviours the path needs.
 struct Earth {
   int32_t calc;       // 0 AzEq, 1 FlDs, 2 Spherical, 3 Ellipsoid     (coords_at_dist_calc, mod.rs:114-145)
-  int32_t flat_dirs;  // world_directions / as_cartesian flat family  (mod.rs:31-57,59-93)
+  int32_t flat_dirs;  // bit 0: world_directions / as_cartesian flat family  (mod.rs:31-57,59-93); bit 1: EARTH_FAST_DIV
   int32_t cart;       // 0 flat, 1 spherical(cart_radius), 2 ellipsoid(a,b)
   int32_t spherical;  // EarthShape::Spherical{shape_radius} vs Flat  (to_shape, mod.rs:95-112)
   double calc_radius; // SphericalCalc radius
@@ -463,6 +624,12 @@ struct Earth {
   double a, b;
   double shape_radius;
 };
+// bit 1 of Earth::flat_dirs: x / calc_radius may take dm_div — the radius and every stepper distance x lie within 1e-30 .. 1e30
+// (atmrt_set_params).  A bit of an existing field, not a new one: at 56 bytes the struct is passed to the out-of-line object code
+// (close_mask_impl, atmrt_march_impl.h) in registers; at 64 bytes hipcc 7.2 passes it through scratch, and with -disable-machine-licm
+// the general tracer then lost every object (golden case c5_rect_objects_opaque: 144 trace points instead of 574).
+constexpr int32_t EARTH_FLAT_DIRS = 1, EARTH_FAST_DIV = 2;
+static_assert(sizeof(Earth) == 56, "Earth is passed by value to out-of-line device functions: keep it at 14 dwords");
 
 ATMRT_HD int earth_resolve(const atmrt_earth_model_t& m, Earth& e) {
   e.calc_radius = e.cart_radius = e.a = e.b = e.shape_radius = 0.0;
@@ -509,7 +676,7 @@ ATMRT_HD void spherical_directions(double lat, double lon, Vec3& dirn, Vec3& dir
 
 // EarthModel::world_directions, mod.rs:31-57
 ATMRT_HD void world_directions(const Earth& e, double lat, double lon, Vec3& n, Vec3& ea, Vec3& up) {
-  if (e.flat_dirs) {
+  if (e.flat_dirs & EARTH_FLAT_DIRS) {
     double sinlon, coslon;
     dm_sincos(dm_to_radians(lon), &sinlon, &coslon);
     n = v3(-coslon, -sinlon, 0.0);
@@ -600,7 +767,7 @@ ATMRT_HD void dircalc_new(const Earth& e, double lat, double lon, double dir, Di
 // DirectionalCalc::coords_at_dist
 ATMRT_HD void coords_at_dist(const Earth& e, const DirCalc& c, double dist, double& lat, double& lon) {
   if (e.calc == 2) { // SphericalCalc, directional_calc.rs:72-85
-    double ang = dm_div(dist, e.calc_radius);
+    double ang = (e.flat_dirs & EARTH_FAST_DIV) ? dm_div(dist, e.calc_radius) : dist / e.calc_radius;
     double sinang, cosang;
     dm_sincos(ang, &sinang, &cosang);
     double fx = c.pos.x * cosang + c.dir.x * sinang;
@@ -774,24 +941,69 @@ ATMRT_HD void stepper_init(Stepper& s, bool spherical, double radius, double h0,
   }
 }
 
+// The right-hand side proper.  FAST: n came from a certified interval (1 <= n <= 2^9, |dn| <= 2^15, and in the spherical model
+// a = radius + h >= 1000 m, <= 2^25 m, both part of the certificate) and |b| <= 2^100, which keeps every operand and quotient
+// of the three divisions inside dm_div's range; anything else divides in IEEE.
+constexpr double ACCEL_FAST_MAX_B = 1.2676506002282294e30; // 2^100
+template <bool FAST>
+ATMRT_HD double accel_rhs(bool spherical, double a, double b, double n, double dn) {
+  if (spherical) return a + div_sel<FAST>(2.0 * b * b, a) + div_sel<FAST>((a * a + b * b) * dn, n);
+  return div_sel<FAST>((1.0 + b * b) * dn, n);
+}
+// The generic right-hand side: per-lane layer search, IEEE operations — any atmosphere, any state.  On the GPU it runs for the few
+// steps in which a wavefront straddles a layer boundary, and all the time only in pathological atmospheres.  (Inline: as a call it
+// costs the hot path 2 % — live ranges split around the call site.)
 template <bool CUBIC>
-ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b, int& hint) {
-  if (spherical) {
-    double h = a - radius;
-    double n, dn;
-    refr_n_dn_hint<CUBIC>(atm, h, hint, n, dn);
-    return a + dm_div(2.0 * b * b, a) + dm_div((a * a + b * b) * dn, n);
-  }
-  double n, dn;
-  refr_n_dn_hint<CUBIC>(atm, a, hint, n, dn);
-  return dm_div((1.0 + b * b) * dn, n);
+ATMRT_HD double ray_accel_generic(const AtmTable& a, bool spherical, double radius, double pa, double pb, int& hint) {
+  const double eps = 0.01;
+  const double h = spherical ? pa - radius : pa, h1 = h - eps, h2 = h + eps;
+  const int k = atm_layer(a, h), k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
+  hint = k; // the hint follows the lane, so that the fast path resumes once the wavefront is back inside one certified interval
+  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k1], a.hb[k1], a.tb[k1], a.pb[k1], a.lapse[k1], a.c2[k1], a.c3[k1], a.expo[k1], h1);
+  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k2], a.hb[k2], a.tb[k2], a.pb[k2], a.lapse[k2], a.c2[k2], a.c3[k2], a.expo[k2], h2);
+  const double dn = (n2 - n1) / (2.0 * eps);
+  return accel_rhs<false>(spherical, pa, pb, n, dn);
 }
 
-// PathStepper::next: the state after one more step of `step` metres in x.  `accel(spherical, radius, a, b, hint)` is
-// the right-hand side of the ODE; the GPU path kernel substitutes a version that spreads its n(h) evaluations over lanes.
+// The stepper's right-hand side.  When every active lane's three evaluation points (h, h -+ eps: 1 cm apart) lie in the certified
+// part of the hinted layer and |b| <= 2^100 — the normal case: rays stay below 11 km in a physical atmosphere — one vote, one set of
+// scalar layer parameters and the shortcut divisions serve the whole stage, and the instruction streams of the three evaluations
+// interleave (the table look-ups of exp/log are the long latencies here).  Otherwise the generic version, same value.
+// `fast` (wave-uniform) reports which version ran.
+template <bool CUBIC>
+ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, double a, double b, int& hint, bool& fast) {
+  fast = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double eps = 0.01;
+  const double h = spherical ? a - radius : a, h1 = h - eps, h2 = h + eps;
+  const int ku = __builtin_amdgcn_readfirstlane(hint);
+  // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
+  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
+  const ConstTable ka = (ConstTable)(uintptr_t)&atm;
+  if (__all(h1 >= ka->safe_lo[ku] && h2 < ka->safe_hi[ku] && !(dm_fabs(b) > ACCEL_FAST_MAX_B))) {
+    const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], rtb = ka->rtb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
+                 c3 = ka->c3[ku], expo = ka->expo[ku];
+    const int cubic = ka->cubic[ku];
+    double n, n1, n2;
+    refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
+    const double dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
+    fast = true;
+    return accel_rhs<true>(spherical, a, b, n, dn);
+  }
+#endif
+  return ray_accel_generic<CUBIC>(atm, spherical, radius, a, b, hint);
+}
+
+// PathStepper::next: the state after one more step of `step` metres in x.  `accel(spherical, radius, a, b, hint, fast)` is
+// the right-hand side of the ODE.  tame (wave-uniform on the GPU): all four stages ran certified (ray_accel's `fast`) — the start
+// altitude then lies in a certified interval (radius + h >= 1000 m) and every stage slope is at most 2^100, so that the altitude
+// change of the step is below 2^100 step: enough for calc_dist's shortcuts without another look at the end state.  Straight rays
+// (closed form, no stages) report false; their callers test the altitudes (calc_dist_in_band).
 template <class Accel>
-ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, bool straight, double step, const Accel& accel) {
+ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, bool straight, double step, const Accel& accel, bool& tame) {
   RayState out;
+  tame = false;
   if (straight) {
     s.x = s.x + step;
     if (spherical) {
@@ -810,14 +1022,16 @@ ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, b
   double d = spherical ? step / radius : step;
   double half = 0.5 * d, sixth = d / 6.0;
   double a = s.a, b = s.b;
+  bool f1, f2, f3, f4;
   double k1a = b;
-  double k1b = accel(spherical, radius, a, b, s.hint);
+  double k1b = accel(spherical, radius, a, b, s.hint, f1);
   double k2a = b + half * k1b;
-  double k2b = accel(spherical, radius, a + half * k1a, k2a, s.hint);
+  double k2b = accel(spherical, radius, a + half * k1a, k2a, s.hint, f2);
   double k3a = b + half * k2b;
-  double k3b = accel(spherical, radius, a + half * k2a, k3a, s.hint);
+  double k3b = accel(spherical, radius, a + half * k2a, k3a, s.hint, f3);
   double k4a = b + d * k3b;
-  double k4b = accel(spherical, radius, a + d * k3a, k4a, s.hint);
+  double k4b = accel(spherical, radius, a + d * k3a, k4a, s.hint, f4);
+  tame = f1 && f2 && f3 && f4;
   s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
   s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
   s.x = s.x + step;
@@ -835,14 +1049,18 @@ ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, b
 template <bool CUBIC>
 struct SerialAccel {
   const AtmTable& atm;
-  ATMRT_HD double operator()(bool spherical, double radius, double a, double b, int& hint) const {
-    return ray_accel<CUBIC>(atm, spherical, radius, a, b, hint);
+  ATMRT_HD double operator()(bool spherical, double radius, double a, double b, int& hint, bool& fast) const {
+    return ray_accel<CUBIC>(atm, spherical, radius, a, b, hint, fast);
   }
 };
 template <bool CUBIC = true>
-ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight,
-                               double step) {
-  return stepper_next_with(s, spherical, radius, straight, step, SerialAccel<CUBIC>{atm});
+ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight, double step, bool& tame) {
+  return stepper_next_with(s, spherical, radius, straight, step, SerialAccel<CUBIC>{atm}, tame);
+}
+template <bool CUBIC = true>
+ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, double radius, bool straight, double step) {
+  bool tame;
+  return stepper_next_with(s, spherical, radius, straight, step, SerialAccel<CUBIC>{atm}, tame);
 }
 ATMRT_HD bool atm_has_cubic(const AtmTable& a) {
   for (int k = 0; k < a.n; k++)
@@ -851,14 +1069,33 @@ ATMRT_HD bool atm_has_cubic(const AtmTable& a) {
 }
 
 // calc_dist, utils.rs:42-53
-ATMRT_HD double calc_dist(bool spherical, double radius, double x0, double h0, double x1, double h1) {
+// `fast` (wave-uniform on the GPU): the step was tame (stepper_next_with: h0 + radius >= 1000 m, |dh| <= 2^100 step), or — straight
+// rays — both altitudes lie in [AtmTable::alt_lo, alt_hi].  Every caller advances by one simulation step (dx > 0, 1 mm .. 1e8 m or
+// nothing is certified; likewise the radius), so the radicand then is inside dm_sqrt_inrange's range: at most 2^260, and at least
+// dx^2 (flat), or (spherical) dh^2 >= 1e6 when the mean radius fell below half the start radius, (dx / radius * 500)^2 otherwise.
+// Anything else (a ray that left for 1e300 m, NaN): the IEEE square root.
+ATMRT_HD bool calc_dist_in_band(const AtmTable& atm, double h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
+  const ConstTable ka = (ConstTable)(uintptr_t)&atm;
+  return h >= ka->alt_lo && h <= ka->alt_hi;
+#else
+  return h >= atm.alt_lo && h <= atm.alt_hi;
+#endif
+}
+ATMRT_HD double calc_dist(bool spherical, double radius, double x0, double h0, double x1, double h1, bool fast) {
   double dx = x1 - x0;
   double dh = h1 - h0;
-  // every caller advances by one simulation step: dx > 0 (validated by atmrt_set_params), so the radicand is positive and finite
-  if (!spherical) return dm_sqrt_inrange(dx * dx + dh * dh);
+  if (fast) {
+    if (!spherical) return dm_sqrt_inrange(dx * dx + dh * dh);
+    double avg_h = (h1 + h0) / 2.0;
+    double dx2 = dm_div(dx, radius) * (avg_h + radius);
+    return dm_sqrt_inrange(dx2 * dx2 + dh * dh);
+  }
+  if (!spherical) return dm_sqrt(dx * dx + dh * dh);
   double avg_h = (h1 + h0) / 2.0;
-  double dx2 = dm_div(dx, radius) * (avg_h + radius);
-  return dm_sqrt_inrange(dx2 * dx2 + dh * dh);
+  double dx2 = dx / radius * (avg_h + radius);
+  return dm_sqrt(dx2 * dx2 + dh * dh);
 }
 
 // ---------------------------------------------------------------------------------------------

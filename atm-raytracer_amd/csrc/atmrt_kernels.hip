@@ -1314,16 +1314,24 @@ __global__ void k_atm_sample(Frame f, size_t n, const double* alt, double* t, do
   if (i >= n) return;
   t[i] = atm_temperature(*f.atm, alt[i]);
   p[i] = atm_pressure(*f.atm, alt[i]);
-  nidx[i] = refr_n(*f.atm, alt[i]);
-  dn[i] = refr_dn(*f.atm, alt[i]);
+  // n and dn/dh through the steppers' own evaluation (the first call finds the lane's layer, the second then takes the certified
+  // shortcut path when the whole wavefront sits in one certified interval, the IEEE path otherwise): same values as refr_n / refr_dn
+  int hint = 0;
+  double nv, dv;
+  refr_n_dn_hint<true>(*f.atm, alt[i], hint, nv, dv);
+  refr_n_dn_hint<true>(*f.atm, alt[i], hint, nv, dv);
+  nidx[i] = nv;
+  dn[i] = dv;
 }
 __global__ void k_coords_at_dist(Frame f, double lat0, double lon0, double dir, size_t n, const double* dist, double* lat,
                                  double* lon) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  Earth e = f.earth;
+  e.flat_dirs &= ~EARTH_FAST_DIV; // arbitrary distances here, not a stepper's
   DirCalc c;
-  dircalc_new(f.earth, lat0, lon0, dir, c);
-  coords_at_dist(f.earth, c, dist[i], lat[i], lon[i]);
+  dircalc_new(e, lat0, lon0, dir, c);
+  coords_at_dist(e, c, dist[i], lat[i], lon[i]);
 }
 
 // detmath.h element-wise (atmrt_math_probe): the GPU's instruction sequences against the host's on arbitrary operands

@@ -13,7 +13,9 @@ __shared__ double atmrt_dm_tables_lds[768];
 // In this translation unit the per-object collision code and the proximity filter of a sample are called out of line: they run at
 // a few per cent of the marching steps, and inlined they push the general tracer to 256 VGPRs (2 waves per SIMD; config 5:
 // 559 ms inlined at 2 waves, 507 ms out of line at 3 waves, 680 ms at 4 waves with the spills that needs).
+#ifndef ATMRT_OBJ_FN
 #define ATMRT_OBJ_FN __attribute__((noinline))
+#endif
 #include "atmrt_device.h"
 
 namespace atmrt {
@@ -131,8 +133,10 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
       double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh = alt, path_length = 0.0;
       for (int i = 1;; i++) {
-        RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step);
-        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h);
+        bool tame;
+        RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
+        if (straight) tame = __all(calc_dist_in_band(*f.atm, sh) && calc_dist_in_band(*f.atm, st.h));
+        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h, tame);
         sx = st.x;
         sh = st.h;
         if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
@@ -360,8 +364,10 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
       double sx = 0.0, sh_ = alt, path_length = 0.0;
       bool have0 = true; // lat0 / lon0 / te0 hold the previous sample's geodesic point and terrain elevation
       for (int i = 1;; i++) {
-        RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step);
-        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h);
+        bool tame;
+        RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
+        if (straight) tame = __all(calc_dist_in_band(*f.atm, sh_) && calc_dist_in_band(*f.atm, st.h));
+        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h, tame);
         sx = st.x;
         sh_ = st.h;
         if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)

@@ -27,42 +27,56 @@ struct OctetRK4 {
 
   // n and dn at position `pos` for both stage groups: this lane evaluates its share, everyone receives both results
   __device__ __forceinline__ void eval(bool spherical, double radius, double pos_a, double pos_b, int& hint, double& n_a,
-                                       double& dn_a, double& n_b, double& dn_b) const {
+                                       double& dn_a, double& n_b, double& dn_b, bool& certified) const {
     const double eps = 0.01;
     const double pos = (sub & 4) ? pos_b : pos_a;
     const double h = spherical ? pos - radius : pos;
     const int e = sub & 3;
     const double hh = e == 1 ? h - eps : e == 2 ? h + eps : h;
-    const double nv = refr_n_hint<CUBIC>(atm, hh, hint);
+    const double nv = refr_n_speculative<CUBIC>(atm, hh, hint, certified);
     n_a = __shfl(nv, base, 64);
     const double a1 = __shfl(nv, base + 1, 64), a2 = __shfl(nv, base + 2, 64);
     n_b = __shfl(nv, base + 4, 64);
     const double b1 = __shfl(nv, base + 5, 64), b2 = __shfl(nv, base + 6, 64);
+    // shortcut divisions whether or not every lane was certified: next() discards the step if one was not
     dn_a = dm_div(a2 - a1, 2.0 * eps);
     dn_b = dm_div(b2 - b1, 2.0 * eps);
   }
   static __device__ __forceinline__ double accel(bool spherical, double a, double b, double n, double dn) {
-    if (spherical) return a + dm_div(2.0 * b * b, a) + dm_div((a * a + b * b) * dn, n);
-    return dm_div((1.0 + b * b) * dn, n);
+    return accel_rhs<true>(spherical, a, b, n, dn);
   }
 
-  // PathStepper::next, identical in value to stepper_next_with
-  __device__ __forceinline__ RayState next(Stepper& s, bool spherical, double radius, bool straight, double step) const {
-    if (straight) return stepper_next_with(s, spherical, radius, true, step, SerialAccel<CUBIC>{atm});
+  // PathStepper::next, identical in value to stepper_next_with; tame: as stepper_next_with reports it.
+  // The step is computed with the shortcut divisions throughout and their contract is verified after the fact: every n of every
+  // lane from a certified interval (eval's flag) and the four stage slopes at most 2^100 — stage i is exact if its slope k_ia is in range,
+  // k_1a is the start state and each later slope comes from exact earlier stages, so if all four pass all four stages were exact.
+  // Otherwise (a wavefront straddling a layer boundary for a few steps; a pathological atmosphere) the step is thrown away and
+  // repeated by the serial stepper with its per-stage guards.  One vote per step on this kernel's dependent chain.
+  __device__ __forceinline__ RayState next(Stepper& s, bool spherical, double radius, bool straight, double step, bool& tame) const {
+    if (straight) return stepper_next_with(s, spherical, radius, true, step, SerialAccel<CUBIC>{atm}, tame);
     const double d = spherical ? step / radius : step;
     const double half = 0.5 * d, sixth = d / 6.0;
     const double a = s.a, b = s.b;
+    const int hint0 = s.hint;
     double n1, dn1, n2, dn2, n3, dn3, n4, dn4;
+    bool cert12, cert34; // per lane
     const double k1a = b;
-    eval(spherical, radius, a, a + half * k1a, s.hint, n1, dn1, n2, dn2);
+    eval(spherical, radius, a, a + half * k1a, s.hint, n1, dn1, n2, dn2, cert12);
     const double k1b = accel(spherical, a, b, n1, dn1);
     const double k2a = b + half * k1b;
     const double k2b = accel(spherical, a + half * k1a, k2a, n2, dn2);
     const double k3a = b + half * k2b;
-    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, n3, dn3, n4, dn4);
+    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, n3, dn3, n4, dn4, cert34);
     const double k3b = accel(spherical, a + half * k2a, k3a, n3, dn3);
     const double k4a = b + d * k3b;
     const double k4b = accel(spherical, a + d * k3a, k4a, n4, dn4);
+    const bool slopes_ok = !(dm_fabs(k1a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k2a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k3a) > ACCEL_FAST_MAX_B) &&
+                           !(dm_fabs(k4a) > ACCEL_FAST_MAX_B);
+    if (!__all(slopes_ok && cert12 && cert34)) {
+      s.hint = hint0;
+      return stepper_next_with(s, spherical, radius, false, step, SerialAccel<CUBIC>{atm}, tame);
+    }
+    tame = true;
     s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
     s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
     s.x = s.x + step;
@@ -129,8 +143,10 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   // the wavefront takes part in every shuffle.
   const int i_last = i_end < f.n_path_cap ? i_end : f.n_path_cap;
   for (int i = i_begin; i < i_last; i++) {
-    RayState st = rk4.next(s, sph, radius, straight, step);
-    path_length += calc_dist(sph, radius, px, ph, st.x, st.h);
+    bool tame;
+    RayState st = rk4.next(s, sph, radius, straight, step, tame);
+    if (straight) tame = __all(calc_dist_in_band(*f.atm, ph) && calc_dist_in_band(*f.atm, st.h));
+    path_length += calc_dist(sph, radius, px, ph, st.x, st.h, tame);
     if (!done) {
       if (writer) {
         pelev[base + n] = st.h;

@@ -29,6 +29,37 @@ int ch_cart(const atmrt_earth_model_t* m, double lat, double lon, double elev, d
   for (int i = 0; i < 12; i++) out12[i] = v[i];
   return 0;
 }
+// atm_certify: the altitude interval of every segment inside which the GPU may take its shortcut divisions, and an independent check
+// of the certificate: min T, max p/T, max |Z - 1| and max n over a dense sample of the interval
+int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, double radius, double step, int* n_seg, double* from,
+               double* safe_lo, double* safe_hi, double* band2, double* min_t, double* max_pt, double* max_z_dev, double* max_n) {
+  AtmTable a;
+  if (atm_compile(*def, wavelength, a)) return -1;
+  atm_certify(a, spherical != 0, radius, step);
+  *n_seg = a.n;
+  band2[0] = a.alt_lo;
+  band2[1] = a.alt_hi;
+  for (int k = 0; k < a.n; k++) {
+    from[k] = a.from[k];
+    safe_lo[k] = a.safe_lo[k];
+    safe_hi[k] = a.safe_hi[k];
+    min_t[k] = 1e300; max_pt[k] = max_z_dev[k] = max_n[k] = 0.0;
+    if (!(a.safe_lo[k] < a.safe_hi[k])) continue;
+    const int N = 4000;
+    for (int i = 0; i <= N; i++) {
+      double h = a.safe_lo[k] + (a.safe_hi[k] - a.safe_lo[k]) * i / N;
+      double t = atm_seg_temperature(a, k, h), pr = a.pb[k] * atm_pressure_ratio(a, k, h), pt = pr / t, c = t - 273.15;
+      double z = 1.0 - pt * (1.58123e-6 + c * (-2.9331e-8 + c * 1.1043e-10)) + pt * pt * 1.83e-11;
+      double n = refr_n_layer(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+      if (!(t >= min_t[k])) min_t[k] = t;
+      if (!(pt <= max_pt[k])) max_pt[k] = pt;
+      double zd = z > 1.0 ? z - 1.0 : 1.0 - z;
+      if (!(zd <= max_z_dev[k])) max_z_dev[k] = zd;
+      if (!(n <= max_n[k])) max_n[k] = n;
+    }
+  }
+  return 0;
+}
 int ch_ray_path(const atmrt_atmosphere_t* def, const atmrt_earth_model_t* m, double wavelength, double h0, double ang_deg, int straight,
                 double step, size_t n_steps, double* x, double* h) {
   AtmTable a;

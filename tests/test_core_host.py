@@ -96,3 +96,62 @@ def test_pixel_to_ray_mapping(core, oracle_det):
             assert np.array_equal(res["elevation_angle"], np.broadcast_to(fe[:, None], (p.height, p.width)))
         else:
             assert np.array_equal(res["azimuth"], rd * (180.0 / np.pi)) and np.array_equal(res["elevation_angle"], re * (180.0 / np.pi))
+
+
+WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
+               "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [
+                   [-500.0, 295.22010975963303], [16672.2152178729, 192.93808594359285], [16688.49864235047, 195.36762037322703],
+                   [21728.827855811145, 170.01112581350702], [28892.825051123004, 125.19791348512327]]}}}
+
+
+def _certify(core, atm, spherical=True, radius=6371000.0, step=50.0, wavelength=530e-9):
+    n = C.c_int(0)
+    arrs = [np.zeros(64) for _ in range(7)]
+    band = np.zeros(2)
+    assert core.ch_certify(C.byref(atm), C.c_double(wavelength), int(spherical), C.c_double(radius), C.c_double(step), C.byref(n),
+                           ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(band), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(arrs[6])) == 0
+    keys = ("from", "safe_lo", "safe_hi", "min_t", "max_pt", "max_z_dev", "max_n")
+    return {k: a[:n.value] for k, a in zip(keys, arrs)}, band
+
+
+def test_certified_intervals_cover_the_standard_atmosphere(core):
+    """atm_certify (atmrt_core.h): the GPU takes its shortcut divisions (dm_div, dm_div3, dm_sqrt_inrange: IEEE results for in-range
+    operands only) inside [safe_lo, safe_hi) of a segment and IEEE operations outside.  US-76: every layer is certified from its lower
+    to its upper boundary — the marching kernels never leave the fast path below the point where the last layer's extrapolated
+    temperature reaches 1 K (178 km) — and the lowest layer down to where Z leaves [0.5, 1.5] (-47 km)."""
+    c, band = _certify(core, config.us76())
+    bounds = [11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0]
+    assert list(c["safe_hi"][:6]) == bounds and list(c["safe_lo"][1:]) == bounds
+    assert -60000.0 < c["safe_lo"][0] < -30000.0 and 170000.0 < c["safe_hi"][6] < 180000.0
+    assert band[0] == -100000.0 and band[1] == 1.0e7
+    # an independent dense sample of the certified intervals stays far inside the shortcuts' range
+    assert c["min_t"].min() >= 1.0 and c["max_z_dev"].max() <= 0.5 and c["max_n"].max() < 2.0 and c["max_pt"].max() < 2.0e5
+    # a planet of 10 km: the band ends 1 km above its centre; a radius, step or wavelength outside the supported span: nothing certified
+    c, band = _certify(core, config.us76(), radius=10000.0)
+    assert band[0] == -9000.0 and c["safe_lo"][0] == -9000.0
+    for kw in ({"radius": 10.0}, {"step": 1e-6}, {"step": 1e12}, {"radius": 1e300}):
+        c, band = _certify(core, config.us76(), **kw)
+        assert np.all(c["safe_lo"] == np.inf) and np.all(c["safe_hi"] == -np.inf) and band[0] == np.inf
+    c, band = _certify(core, config.us76(), spherical=False, radius=0.0)  # flat earth shapes have no radius to respect
+    assert list(c["safe_hi"][:6]) == bounds
+
+
+def test_a_spline_that_overshoots_is_certified_only_where_it_is_tame(core):
+    """Two knots 16 m apart with 2.4 K between them make a Natural spline swing below 0 K in the intervals next to them (found by the
+    random sweep, seed 4899): T = 36 K and p = 1.7e308 Pa at 15.5 km.  Those knot intervals must carry no certificate (the kernels
+    then divide in IEEE there); whatever is certified must pass the independent dense sample."""
+    cfg = config.Config.from_dict({"atmosphere": WILD_SPLINE, "output": {"width": 8, "height": 8}})
+    c, band = _certify(core, cfg.atmosphere, spherical=False, radius=0.0)
+    # segments: continuation below -500 m, four knot intervals, continuation above 28.9 km
+    assert len(c["from"]) == 6
+    certified = c["safe_lo"] < c["safe_hi"]
+    assert c["safe_lo"][1] == -500.0 and 2000.0 < c["safe_hi"][1] < 4000.0, "the first knot interval: only below the point where T falls to 1 K"
+    assert not certified[2] and not certified[3] and not certified[4], "their base pressure has overflowed already"
+    for k in np.flatnonzero(certified):
+        assert c["min_t"][k] >= 1.0 and c["max_z_dev"][k] <= 0.5 and c["max_n"][k] < 2.0
+    # a physical spline (troposphere + inversion) is certified knot to knot
+    tame = {"pressure": {"altitude": 0.0, "pressure": 101325.0}, "first_temperature_function": {"Spline": {"boundary_condition": "Natural",
+            "points": [[0.0, 288.0], [1000.0, 283.0], [1200.0, 285.0], [5000.0, 260.0], [11000.0, 217.0], [20000.0, 217.0]]}}}
+    cfg = config.Config.from_dict({"atmosphere": tame, "output": {"width": 8, "height": 8}})
+    c, _ = _certify(core, cfg.atmosphere)
+    assert list(c["safe_lo"][1:6]) == [0.0, 1000.0, 1200.0, 5000.0, 11000.0] and list(c["safe_hi"][1:6]) == [1000.0, 1200.0, 5000.0, 11000.0, 20000.0]

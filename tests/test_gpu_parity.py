@@ -313,6 +313,59 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
 
 
+WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
+               "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [
+                   [-500.0, 295.22010975963303], [16672.2152178729, 192.93808594359285], [16688.49864235047, 195.36762037322703],
+                   [21728.827855811145, 170.01112581350702], [28892.825051123004, 125.19791348512327]]}}}
+
+
+@pytest.mark.parametrize("earth", ["FlatDistorted", "SimpleSphere"])
+def test_pathological_atmosphere_is_still_bit_exact(gpu_ctx, oracle_det, earth):
+    """Seed 4899 of the random sweep: a Natural spline through two knots 16 m apart swings to 36 K at 15.5 km and below 0 K beyond, the
+    hydrostatic pressure reaches 1.7e308 Pa and then inf / NaN.  The GPU's shortcut divisions (dm_div ...: the IEEE quotient for operands
+    with |exponent| < 500) returned NaN for n(h) where the host's IEEE division returns 1.0, and a ray that wandered into that zone
+    took another path.  Since then the shortcuts run only inside altitude intervals in which atm_certify proves the operands tame, and
+    IEEE operations everywhere else: the sampler, the integrator and whole frames must match the oracle to the bit (NaN as NaN)."""
+    import ctypes as C
+    from atm_raytracer_amd import config, generators
+    from util import bits
+    doc = {"view": {"position": {"latitude": 46.68895508040043, "longitude": 8.336055024224262, "altitude": {"Absolute": 3342.573230139556}},
+                    "frame": {"direction": 180.0, "tilt": -20.804093573300673, "fov": 17.672070693357174, "max_distance": 50394.203235634996}},
+           "earth_shape": earth, "straight_rays": False, "simulation_step": 50.0, "wavelength": 6.52274204561565e-07,
+           "atmosphere": WILD_SPLINE, "scene": {"terrain_alpha": 1.0}, "output": {"width": 28, "height": 30, "generator": "Fast"}}
+    cfg = config.Config.from_dict(doc)
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(cfg.params)))
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(cfg.atmosphere)))
+    try:
+        # the sampler across the tame part, the edge of the certificate (3.1 km), the overflow zone and the NaN zone; in runs of 64 equal
+        # altitudes too, so that whole wavefronts sit inside one interval and take the certified path where there is one
+        alt = np.concatenate([np.linspace(-600.0, 30000.0, 6121), np.linspace(3100.0, 3170.0, 1401), np.linspace(15499.2, 15499.4, 401),
+                              np.repeat(np.linspace(-400.0, 17000.0, 120), 64)])
+        got = generators.atmosphere_sample(gpu_ctx, alt)
+        env = oracle_det.env(cfg.atmosphere, cfg.params.wavelength)
+        want = {"temperature": [oracle_det.temperature(env, h) for h in alt], "pressure": [oracle_det.pressure(env, h) for h in alt],
+                "n": [oracle_det.n(env, h) for h in alt], "dn_dh": [oracle_det.dn(env, h) for h in alt]}
+        for k in want:
+            bad = np.flatnonzero(bits(got[k]) != bits(np.array(want[k], dtype=np.float64)))
+            assert bad.size == 0, (k, bad.size, alt[bad[:4]], got[k][bad[:4]], np.array(want[k])[bad[:4]])
+        assert np.isnan(want["n"]).any() and np.isfinite(want["n"]).any() and (np.array(want["pressure"]) > 1e300).any()
+        # the integrator: rays that dive into the wild zone (the three of the failing row and its neighbours) and rays that do not
+        ang = np.array([-26.48440201045119, -27.1, -25.8, -12.0, -2.0, 0.0, 1.5, 20.0, 60.0])
+        x, h = generators.ray_paths(gpu_ctx, 3342.573230139556, ang, 50.0, 1100, False)
+        xo, ho = oracle_det.ray_paths(cfg.params, 3342.573230139556, ang, 50.0, 1100, False, cfg.atmosphere)
+        assert np.array_equal(bits(x), bits(xo)) and np.array_equal(bits(h), bits(ho))
+        assert np.isnan(ho).any()
+        # whole frames, every generator
+        tiles = synth.synth_tiles([46], [8], level=301)
+        for gen, w, hh in (("Fast", 28, 30), ("Rectilinear", 28, 24), ("InterpolatingRectilinear", 28, 30)):
+            cfg.params.generator = {"Fast": 0, "InterpolatingRectilinear": 1, "Rectilinear": 2}[gen]  # atmrt_generator_kind
+            cfg.params.width, cfg.params.height = w, hh
+            assert_bitexact(run_gpu(gpu_ctx, cfg, tiles), run_oracle(oracle_det, cfg, tiles))
+    finally:
+        us = config.us76()
+        gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(us)))
+
+
 def _nested_cylinders(cfg, n, lat=46.53, lon=8.5, r0=4.0, dr=3.0, alpha=0.5):
     """n concentric translucent cylinders on one spot: a ray through them collects up to 2 n points inside ONE 100 m step."""
     from atm_raytracer_amd import _abi

@@ -32,8 +32,13 @@ def run_oracle(oracle, cfg, tiles, n_threads=0, rows=None):
 
 
 def bits(a):
+    """The bit pattern of every element; NaNs (any payload, either sign: x86 and gfx950 generate different ones) as one value."""
     a = np.ascontiguousarray(a)
-    return a.view(np.uint64) if a.dtype == np.float64 else a
+    if a.dtype != np.float64:
+        return a
+    u = a.view(np.uint64).copy()
+    u[np.isnan(a)] = 0x7FF8000000000000
+    return u
 
 
 def assert_bitexact(got, want):

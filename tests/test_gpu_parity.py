@@ -366,6 +366,36 @@ def test_pathological_atmosphere_is_still_bit_exact(gpu_ctx, oracle_det, earth):
         gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(us)))
 
 
+UNCERTIFIED = [  # earth model, step, max_distance, observer height above the terrain, tilt
+    ({"Spherical": {"radius": 500.0}}, 0.02, 4.0, 2.0, -20.0),
+    ({"Spherical": {"radius": 3.0e13}}, 50.0, 6_000.0, 30.0, -6.0),
+    ("SimpleSphere", 2.0e-4, 0.05, 0.01, -30.0),
+    ({"ObserverAe": {"proj_radius": 1.0e-40}}, 50.0, 6_000.0, 30.0, -6.0),
+]
+
+
+def uncertified_case(case, generator):
+    from atm_raytracer_amd import config
+    earth, step, max_distance, above, tilt = case
+    doc = {"view": {"position": {"latitude": 46.5, "longitude": 8.5, "altitude": {"Relative": above}},
+                    "frame": {"direction": 100.0, "tilt": tilt, "fov": 40.0, "max_distance": max_distance}},
+           "earth_shape": earth, "simulation_step": step, "output": {"width": 24, "height": 16, "generator": generator}}
+    return config.Config.from_dict(doc)
+
+
+@pytest.mark.parametrize("case", UNCERTIFIED, ids=["radius_500m", "radius_3e13m", "step_0.2mm", "proj_radius_1e-40m"])
+@pytest.mark.parametrize("generator", ["Fast", "Rectilinear"])
+def test_uncertified_geometry_runs_on_ieee_operations(gpu_ctx, oracle_det, case, generator):
+    """atm_certify certifies nothing for a planet below 1 km or above 1e12 m or a step below 1 mm, and x / calc_radius leaves dm_div for
+    radii outside 1e-30 .. 1e30: these frames run the generic evaluation (IEEE division and square root in every stage) from the first
+    step to the last and must still match the oracle bit for bit."""
+    cfg = uncertified_case(case, generator)
+    tiles = synth.synth_tiles([46], [8], level=301)
+    want = run_oracle(oracle_det, cfg, tiles)
+    assert want["n_hits"] > 0
+    assert_bitexact(run_gpu(gpu_ctx, cfg, tiles), want)
+
+
 def _nested_cylinders(cfg, n, lat=46.53, lon=8.5, r0=4.0, dr=3.0, alpha=0.5):
     """n concentric translucent cylinders on one spot: a ray through them collects up to 2 n points inside ONE 100 m step."""
     from atm_raytracer_amd import _abi

@@ -50,13 +50,40 @@ namespace atmrt {
 constexpr uint32_t OBJECT_RAY = 0xffffffffu; // hit_count of a ray left to k_rect_trace
 constexpr int WAVE_CAND = 96;                // entries of a wavefront's list; more: every ray of the wavefront is left to the tracer
 
-template <int MODE, int CALC, bool CUBIC>
+// Wave priority against the drain at the end of a launch.  The SIMD issues oldest-wave-first, so the four wavefronts that share a
+// SIMD in the LAST resident set do not finish together: the favoured one runs at its dependency-chain speed, and the last one
+// ends alone on a SIMD it cannot fill (a launch of uniform 2000-step rays takes 4.02 ms per workgroup-per-CU + 3.5 ms: one resident
+// set 19.5 ms, not 16.1).  A wavefront therefore starts at priority 3 and drops one level every DRAIN_PRIO_BAND steps: the
+// wavefronts of a SIMD are kept within a band of one another and the last set drains together (16.8 ms; a shard of the headline at
+// 8 GPUs 41.5 -> 39.0 ms).  In a launch of many resident sets the drain is 1 % and the priorities cost about as much (the headline
+// frame 269.4 -> 271.6 ms), so only launches of at most DRAIN_PRIO_MAX_BLOCKS workgroups (16 resident sets) use them: the kernel is
+// compiled in both variants (DRAIN) and the launcher picks one by the size of its grid (ATMRT_LAUNCH_MARCH).
+#ifndef DRAIN_PRIO_MAX_BLOCKS
+#define DRAIN_PRIO_MAX_BLOCKS 16384u
+#endif
+constexpr int DRAIN_PRIO_BAND = 512;
+// launches k_rect_march<MODE, CALC, CUBIC, DRAIN> over N rays / list entries, DRAIN by the grid size
+#define ATMRT_LAUNCH_MARCH(MODE, N, STREAM, ...)                                                                                       \
+  do {                                                                                                                                 \
+    const unsigned blocks_ = cdiv((size_t)(N), 256);                                                                                   \
+    if (blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                                                            \
+      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, true>), dim3(blocks_), dim3(256), 0, STREAM, \
+                                                            __VA_ARGS__));                                                             \
+    } else {                                                                                                                           \
+      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, false>), dim3(blocks_), dim3(256), 0, STREAM, \
+                                                            __VA_ARGS__));                                                             \
+    }                                                                                                                                  \
+  } while (0)
+
+template <int MODE, int CALC, bool CUBIC, bool DRAIN>
 __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
                                                     const uint32_t* __restrict__ pixel_list, uint32_t n_list) {
   stage_dm_tables();
+  constexpr bool drain_prio = DRAIN;
+  if (drain_prio) __builtin_amdgcn_s_setprio(3);
   const size_t plane = (size_t)f.wl * f.h;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   // MODE 2 may be restricted to a list of pixels (those whose crossings did not fit the slots of the counting march)
@@ -133,6 +160,12 @@ __global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, 
       double re0 = alt, pl0 = 0.0; // TracingState::new(.., first_path.elev, 0.0, 0.0), utils.rs:208
       double sx = 0.0, sh = alt, path_length = 0.0;
       for (int i = 1;; i++) {
+        if (drain_prio && (i & (DRAIN_PRIO_BAND - 1)) == 0) { // see DRAIN_PRIO_MAX_BLOCKS
+          const int band = i / DRAIN_PRIO_BAND;
+          if (band == 1) __builtin_amdgcn_s_setprio(2);
+          else if (band == 2) __builtin_amdgcn_s_setprio(1);
+          else if (band == 3) __builtin_amdgcn_s_setprio(0);
+        }
         bool tame;
         RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
         if (straight) tame = __all(calc_dist_in_band(*f.atm, sh) && calc_dist_in_band(*f.atm, st.h));
@@ -503,19 +536,15 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, n);
   if (f.opaque) {
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<0, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, rec,
-                                                          (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                          (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u));
+    ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                       (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
     (void)hipEventRecord(ev_marched, stream);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
                                                           f, ws.hit_step, rec, out));
   } else {
     RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<1, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, out, ws.hit_step, (const uint64_t*)nullptr, slots,
-                                                          ws.slot_step, (uint32_t*)nullptr,
-                                                          (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u));
+    ATMRT_LAUNCH_MARCH(1, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, (uint32_t*)nullptr,
+                       (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
     (void)hipEventRecord(ev_marched, stream);
   }
 }
@@ -559,10 +588,8 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
   hipLaunchKernelGGL(k_rect_gather_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count, ws.hit_offset,
                      ws.slot_step, slots, ws.list_step, ws.list_pixel, rec, ws.overflow, (unsigned long long*)ws.counters);
   if (ws.n_overflow) {
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<2, CALC, CUBIC>), dim3(cdiv((size_t)ws.n_overflow, 256)), dim3(256), 0,
-                                                          stream, f, dense, ws.hit_step, ws.hit_offset, rec, ws.list_step, ws.list_pixel,
-                                                          (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow,
-                                                          (uint32_t)ws.n_overflow));
+    ATMRT_LAUNCH_MARCH(2, ws.n_overflow, stream, f, dense, ws.hit_step, ws.hit_offset, rec, ws.list_step, ws.list_pixel,
+                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow);
   }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
@@ -586,9 +613,8 @@ template <bool CUBIC>
 void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<3, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
-                                                        ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
-                                                        (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u));
+  ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
+                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
                      (unsigned long long*)ws.counters);
 }

@@ -929,6 +929,11 @@ static int run_interpolating(atmrt_ctx* c, const Frame& f, Workspace& ws, const 
   fl.wl = (int32_t)nd;
   fl.h = (int32_t)ne;
   const size_t nlat = (size_t)nd * ne;
+  // run_core leaves its trace points in d_packed / d_hit_offset, and so must this frame.  The two pairs of buffers trade places
+  // twice per frame — here, before the lattice workspace takes their addresses, and after the lattice pass — so that each pair serves the same role (lattice / image) in every frame
+  // and keeps its capacity: with one swap the roles alternated and the smaller buffer was reallocated in the second frame.
+  std::swap(c->d_packed, c->d_lat_packed);
+  std::swap(c->d_hit_offset, c->d_lat_offset);
   Workspace wsl{};
   int rc = prepare_workspace(c, fl, &wsl);
   if (rc) return rc;
@@ -941,7 +946,7 @@ static int run_interpolating(atmrt_ctx* c, const Frame& f, Workspace& ws, const 
   PackedHits lpacked{};
   uint64_t lhits = 0;
   if ((rc = run_core(c, fl, wsl, ldense, true, &lpacked, &lhits))) return rc;
-  std::swap(c->d_packed, c->d_lat_packed);   // keep the lattice result; the image gets fresh buffers
+  std::swap(c->d_packed, c->d_lat_packed);   // keep the lattice result; the image gets the other pair
   std::swap(c->d_hit_offset, c->d_lat_offset);
   LatticeResult lr{};
   lr.hit_count = ldense.hit_count;

@@ -6,7 +6,7 @@ set -e
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/${1:-gpurun_out/cfgs}
 mkdir -p "$OUT"
-B="python3 $REPO/bench.py --no-cpu-baseline --only --steps 3 --warmup 2"  # warmup 2: the interpolating generator swaps its packed buffers between the lattice frame and the final frame, which settles their capacities in the second frame
+B="python3 $REPO/bench.py --no-cpu-baseline --only --steps 3 --warmup 2"
 $B --scene S3 --step 50 --generator Rectilinear > "$OUT/C3_Rectilinear.json" 2> "$OUT/C3_Rectilinear.err"
 $B --scene S3 --step 50 --generator Fast > "$OUT/C3_Fast.json" 2> "$OUT/C3_Fast.err"
 echo "[configs] C3 done"

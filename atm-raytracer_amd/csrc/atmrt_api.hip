@@ -498,9 +498,9 @@ extern "C" int atmrt_set_atmosphere(atmrt_ctx* c, const atmrt_atmosphere_t* a) {
   int rc = atm_compile(*a, c->params.wavelength, t);
   if (rc) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere definition: %s", why[-rc <= 5 ? -rc : 1]);
   if (!(a->pressure > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "the pressure fixed point must be positive");
-  for (int k = 0; k < t.n; k++)
-    if (!(t.tb[k] > 0.0) || !(t.pb[k] > 0.0) || !std::isfinite(t.pb[k]))
-      return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "atmosphere definition yields a non-positive temperature or pressure");
+  // Nothing derived is validated: a profile that runs through 0 K, or whose hydrostatic pressure overflows, is marched like any
+  // other (NaN and inf propagate as they do in the reference's f64 arithmetic); such segments get no certificate (atm_certify)
+  // and are evaluated with IEEE operations.  Until round 2 they were rejected here.
   c->atm_def = *a;
   return ATMRT_OK;
 }

@@ -259,13 +259,17 @@ EARTHS = ["SimpleSphere", {"Spherical": {"radius": 6371000.0}}, {"Spherical": {"
           {"ObserverAe": {"proj_radius": 6371000.0}}, "SimpleObserverAe"]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("ATMRT_RANDOM_SEEDS", "36"))))
+_SEED0 = int(os.environ.get("ATMRT_RANDOM_SEED_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("ATMRT_RANDOM_SEEDS", "120"))))
 def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     """Seeded random sweep over the parameter space (earth model, direction incl. the 0/360 wrap, tilt, field of view, observer
     altitude kind, non-integer steps whose accumulated distances round, straight / refracted, opaque / translucent, generator,
     wavelength, and — for a third of the seeds — a random atmosphere: 1-4 Linear layers with lapse, isothermal and inversion
     gradients, or a Spline temperature profile — and for a quarter random scene objects): every f64 field and every hit decision must match the oracle bit for bit.
-    ATMRT_RANDOM_SEEDS widens the sweep (1200 seeds pass on the final kernels of round 1)."""
+    ATMRT_RANDOM_SEEDS widens the sweep and ATMRT_RANDOM_SEED_FIRST moves it (round 2: seed 4899 of a 6000-seed sweep found the
+    pathological atmosphere of test_pathological_atmosphere_is_still_bit_exact; seeds 0 .. 15999 pass on the final kernels)."""
     rng = np.random.default_rng(1000 + seed)
     gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
     w, h = int(rng.integers(3, 70)), int(rng.integers(2, 40))
@@ -319,8 +323,17 @@ WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
                    [21728.827855811145, 170.01112581350702], [28892.825051123004, 125.19791348512327]]}}}
 
 
+# seed 31148 of the sweep: the same kind of spline, steeper — the pressure at the base of its upper knot intervals is inf / NaN.
+# Until round 2 atmrt_set_atmosphere rejected it ("non-positive temperature or pressure"); the reference has no such check.
+OVERFLOWING_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 99730.24971796537},
+                      "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [
+                          [-500.0, 295.9785296912339], [13886.76872258016, 216.67442822116288], [13916.894125578941, 207.95894584371578],
+                          [22713.29131575354, 163.34485706767265], [27617.68202733401, 130.8150959041496]]}}}
+
+
+@pytest.mark.parametrize("atmosphere", [WILD_SPLINE, OVERFLOWING_SPLINE], ids=["seed4899", "seed31148"])
 @pytest.mark.parametrize("earth", ["FlatDistorted", "SimpleSphere"])
-def test_pathological_atmosphere_is_still_bit_exact(gpu_ctx, oracle_det, earth):
+def test_pathological_atmosphere_is_still_bit_exact(gpu_ctx, oracle_det, earth, atmosphere):
     """Seed 4899 of the random sweep: a Natural spline through two knots 16 m apart swings to 36 K at 15.5 km and below 0 K beyond, the
     hydrostatic pressure reaches 1.7e308 Pa and then inf / NaN.  The GPU's shortcut divisions (dm_div ...: the IEEE quotient for operands
     with |exponent| < 500) returned NaN for n(h) where the host's IEEE division returns 1.0, and a ray that wandered into that zone
@@ -332,7 +345,7 @@ def test_pathological_atmosphere_is_still_bit_exact(gpu_ctx, oracle_det, earth):
     doc = {"view": {"position": {"latitude": 46.68895508040043, "longitude": 8.336055024224262, "altitude": {"Absolute": 3342.573230139556}},
                     "frame": {"direction": 180.0, "tilt": -20.804093573300673, "fov": 17.672070693357174, "max_distance": 50394.203235634996}},
            "earth_shape": earth, "straight_rays": False, "simulation_step": 50.0, "wavelength": 6.52274204561565e-07,
-           "atmosphere": WILD_SPLINE, "scene": {"terrain_alpha": 1.0}, "output": {"width": 28, "height": 30, "generator": "Fast"}}
+           "atmosphere": atmosphere, "scene": {"terrain_alpha": 1.0}, "output": {"width": 28, "height": 30, "generator": "Fast"}}
     cfg = config.Config.from_dict(doc)
     gpu_ctx.check(gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(cfg.params)))
     gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(cfg.atmosphere)))
@@ -348,7 +361,8 @@ def test_pathological_atmosphere_is_still_bit_exact(gpu_ctx, oracle_det, earth):
         for k in want:
             bad = np.flatnonzero(bits(got[k]) != bits(np.array(want[k], dtype=np.float64)))
             assert bad.size == 0, (k, bad.size, alt[bad[:4]], got[k][bad[:4]], np.array(want[k])[bad[:4]])
-        assert np.isnan(want["n"]).any() and np.isfinite(want["n"]).any() and (np.array(want["pressure"]) > 1e300).any()
+        assert np.isnan(want["n"]).any() and np.isfinite(want["n"]).any()
+        assert (np.array(want["pressure"]) > 1e300).any() or not np.isfinite(want["pressure"]).all()
         # the integrator: rays that dive into the wild zone (the three of the failing row and its neighbours) and rays that do not
         ang = np.array([-26.48440201045119, -27.1, -25.8, -12.0, -2.0, 0.0, 1.5, 20.0, 60.0])
         x, h = generators.ray_paths(gpu_ctx, 3342.573230139556, ang, 50.0, 1100, False)

@@ -317,6 +317,94 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
 
 
+EXTREME_EARTHS = EARTHS + [{"Spherical": {"radius": 2.0e5}}, {"Spherical": {"radius": 6.0e8}}, {"Ellipsoid": {"a": 6378137.0, "b": 5.0e6}},
+                           {"Ellipsoid": {"a": 3.0e6, "b": 3.3e6}}, {"ObserverAe": {"proj_radius": 1.0e6}}]
+
+
+_MOSAIC = {}
+
+
+def _mosaic_2x2():
+    if not _MOSAIC:
+        _MOSAIC.update(synth.synth_tiles([46, 47], [8, 9], level=301))
+    return _MOSAIC
+
+
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("ATMRT_EXTREME_SEEDS", "60"))))
+def test_randomised_extremes(gpu_ctx, oracle_det, seed):
+    """A second seeded sweep over the corners the first one leaves out: views straight up and straight down and fields of view up to
+    170 degrees, observers below the terrain, far above it and below sea level, rays that leave the tile, two-sample rays
+    (max_distance barely above the step) and thousands of short steps, fully transparent terrain (every crossing recorded), splines
+    with Derivatives / SecondDerivatives boundary conditions and lapse rates up to +-50 K/km, small and huge planets and squashed
+    ellipsoids, column shards (col_begin / col_end), objects above, below and around the observer incl. the observer INSIDE a
+    cylinder, translucent and opaque, and 2 x 2 tile mosaics with a missing tile seen from their common corner.  GPU == oracle in
+    every bit."""
+    from atm_raytracer_amd import config, _abi
+    rng = np.random.default_rng(500_000 + seed)
+    gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
+    w, h = int(rng.integers(2, 48)), int(rng.integers(2, 32))
+    if gen == "Rectilinear":
+        w, h = min(w, 32), min(h, 20)
+    alt_kind = str(rng.choice(["Relative", "Absolute", "Absolute"]))
+    alt = float(rng.choice([rng.uniform(0.5, 50.0), rng.uniform(50.0, 9000.0), rng.uniform(-400.0, 0.0), rng.uniform(9000.0, 60000.0)]))
+    step = float(rng.choice([rng.uniform(5.0, 40.0), rng.uniform(40.0, 1500.0), 100.0, 7.3]))
+    n_steps = float(rng.choice([1.2, 2.5, rng.uniform(3.0, 60.0), rng.uniform(60.0, 900.0)]))
+    doc = {
+        "view": {"position": {"latitude": float(rng.choice([rng.uniform(46.01, 46.99), 46.0005, 46.9995])),
+                              "longitude": float(rng.choice([rng.uniform(8.01, 8.99), 8.0005, 8.9995])), "altitude": {alt_kind: alt}},
+                 "frame": {"direction": float(rng.uniform(-400.0, 800.0)), "tilt": float(rng.choice([rng.uniform(-89.0, 89.0), -90.0, 90.0, 0.0])),
+                           "fov": float(rng.choice([rng.uniform(0.01, 20.0), rng.uniform(20.0, 170.0)])), "max_distance": step * n_steps}},
+        "earth_shape": EXTREME_EARTHS[int(rng.integers(len(EXTREME_EARTHS)))],
+        "straight_rays": bool(rng.uniform() < 0.3),
+        "simulation_step": step,
+        "wavelength": float(rng.choice([rng.uniform(300e-9, 1100e-9), 530e-9])),
+        "scene": {"terrain_alpha": float(rng.choice([1.0, 0.5, 0.0, 0.999]))},
+        "output": {"width": w, "height": h, "generator": gen},
+    }
+    u = rng.uniform()
+    if u < 0.35:
+        n_knots = int(rng.integers(2, 9))
+        knots = np.sort(rng.uniform(-1000.0, 40_000.0, n_knots))
+        temps = 288.0 - 0.006 * knots + rng.uniform(-15.0, 15.0, n_knots)
+        bc = rng.choice(["Natural", "Derivatives", "SecondDerivatives"])
+        bcv = "Natural" if bc == "Natural" else {str(bc): [float(rng.uniform(-0.01, 0.01)) if bc == "Derivatives" else float(rng.uniform(-1e-6, 1e-6)),
+                                                           float(rng.uniform(-0.01, 0.01)) if bc == "Derivatives" else float(rng.uniform(-1e-6, 1e-6))]}
+        doc["atmosphere"] = {"pressure": {"altitude": float(rng.uniform(-200.0, 3000.0)), "pressure": float(rng.uniform(300.0, 1100.0)) * 100.0},
+                             "first_temperature_function": {"Spline": {"boundary_condition": bcv, "points": [[float(a), float(t)] for a, t in zip(knots, temps)]}}}
+    elif u < 0.7:
+        grads = [float(rng.choice([-0.0065, 0.0, 0.05, -0.05, -0.0342, float(rng.uniform(-0.02, 0.02)), 1e-9])) for _ in range(int(rng.integers(1, 7)))]
+        alts = np.sort(rng.uniform(-500.0, 50_000.0, len(grads) - 1))
+        doc["atmosphere"] = {"pressure": {"altitude": float(rng.uniform(-300.0, 5000.0)), "pressure": float(rng.uniform(200.0, 1100.0)) * 100.0},
+                             "temperature_fixed_point": {"altitude": float(rng.uniform(-300.0, 12000.0)), "temperature": float(rng.uniform(180.0, 330.0))},
+                             "first_temperature_function": {"Linear": {"gradient": grads[0]}},
+                             "next_functions": [{"altitude": float(a), "function": {"Linear": {"gradient": g}}} for a, g in zip(alts, grads[1:])]}
+    cfg = config.Config.from_dict(doc)
+    if rng.uniform() < 0.5:  # a column shard of the frame
+        c0 = int(rng.integers(0, w))
+        cfg.params.col_begin, cfg.params.col_end = c0, int(rng.integers(c0 + 1, w + 1))
+    if rng.uniform() < 0.45:
+        reach = step * n_steps
+        synth.add_objects(cfg, n_cyl=int(rng.integers(1, 30)), n_bill=int(rng.integers(0, 10)), dist=(0.0, float(max(reach, 30.0))),
+                          spread_deg=float(rng.uniform(1.0, 180.0)), radius=(1.0, float(rng.uniform(5.0, 400.0))), height=(1.0, float(rng.uniform(5.0, 3000.0))),
+                          bill_w=(1.0, 600.0), bill_h=(1.0, 600.0), seed=int(rng.integers(1 << 30)))
+        for o in cfg.objects:  # some objects float or are sunk, some altitudes are absolute
+            if rng.uniform() < 0.3:
+                o.position.altitude = float(rng.uniform(-300.0, 2000.0))
+            if rng.uniform() < 0.2:
+                o.position.altitude_kind = _abi.ALT_ABSOLUTE
+                o.position.altitude = float(rng.uniform(0.0, 5000.0))
+    if rng.uniform() < 0.3:  # a 2 x 2 mosaic with a hole, the observer near the common corner: rays cross tile borders and the hole
+        tiles = dict(_mosaic_2x2())
+        del tiles[sorted(tiles)[int(rng.integers(4))]]
+        cfg.params.position.latitude = float(47.0 + rng.uniform(-0.02, 0.02))
+        cfg.params.position.longitude = float(9.0 + rng.uniform(-0.02, 0.02))
+    else:
+        tiles = synth.synth_tiles([46], [8], level=301)
+    want = run_oracle(oracle_det, cfg, tiles)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert_bitexact(got, want)
+
+
 WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
                "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [
                    [-500.0, 295.22010975963303], [16672.2152178729, 192.93808594359285], [16688.49864235047, 195.36762037322703],

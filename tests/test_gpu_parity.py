@@ -338,7 +338,8 @@ def test_randomised_extremes(gpu_ctx, oracle_det, seed):
     with Derivatives / SecondDerivatives boundary conditions and lapse rates up to +-50 K/km, small and huge planets and squashed
     ellipsoids, column shards (col_begin / col_end), objects above, below and around the observer incl. the observer INSIDE a
     cylinder, translucent and opaque, and 2 x 2 tile mosaics with a missing tile seen from their common corner.  GPU == oracle in
-    every bit."""
+    every bit; then the frame is drawn (k_draw_image) with a random colouring, palette, light, water level and fog: == the
+    oracle's image in every byte."""
     from atm_raytracer_amd import config, _abi
     rng = np.random.default_rng(500_000 + seed)
     gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
@@ -403,6 +404,20 @@ def test_randomised_extremes(gpu_ctx, oracle_det, seed):
     want = run_oracle(oracle_det, cfg, tiles)
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert_bitexact(got, want)
+    # and the image of that frame (renderer::draw_image, renderer/mod.rs:367-414) under a random colouring, byte for byte
+    from atm_raytracer_amd import generators, _abi as abi
+    view = {"fog_distance": float(rng.uniform(1.0, 1.0 + 2.0 * step * n_steps))} if rng.uniform() < 0.5 else {}
+    if rng.uniform() < 0.4:
+        view["coloring"] = {"Simple": {"water_level": float(rng.uniform(-100.0, 3000.0))}}
+    elif rng.uniform() < 0.8:
+        view["coloring"] = {"Shading": {"water_level": float(rng.uniform(-100.0, 3000.0)), "ambient_light": float(rng.uniform(0.0, 1.0)),
+                                        "light_zenith_angle": float(rng.uniform(0.0, 120.0)), "light_dir": float(rng.uniform(-360.0, 360.0)),
+                                        "palette": str(rng.choice(sorted(abi.PALETTES)))}}
+    cfg.coloring = config._coloring(view)
+    col = generators.into_coloring(gpu_ctx.lib, cfg.params, cfg.coloring)
+    ocol = oracle_det.into_coloring(cfg.params, cfg.coloring)
+    assert bytes(col) == bytes(ocol)
+    assert np.array_equal(generators.draw_image(gpu_ctx, col, got["width"], got["height"]), oracle_det.draw_image(want, ocol))
 
 
 WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},

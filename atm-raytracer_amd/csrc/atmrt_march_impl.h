@@ -75,8 +75,16 @@ constexpr int DRAIN_PRIO_BAND = 512;
     }                                                                                                                                  \
   } while (0)
 
+// The DRAIN variant also runs 5 wavefronts per SIMD (96 VGPRs, 136 B of scratch per lane) instead of 4 (127 VGPRs, none): a shard's
+// long wavefronts are 1.37 resident sets of 4096 but 1.09 sets of 5120, so far fewer of them are left to run on half-empty SIMDs at
+// the end (mean occupancy of a shard launch at 8 GPUs 0.83, VALU busy 0.86 with 4 per SIMD): 8 x 39.3 -> 8 x 36.2 ms, 4 x 73.5 ->
+// 4 x 71.2.  The whole frame would gain 1.5 % from 5 per SIMD (2.3 % from 6) and pay for it with the scratch traffic round 1 had
+// (40 x its algorithmic stores): it stays at 4, without scratch.
+#ifndef ATMRT_MARCH_WAVES_SMALL
+#define ATMRT_MARCH_WAVES_SMALL 5
+#endif
 template <int MODE, int CALC, bool CUBIC, bool DRAIN>
-__global__ __launch_bounds__(256, ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+__global__ __launch_bounds__(256, DRAIN ? ATMRT_MARCH_WAVES_SMALL : ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,

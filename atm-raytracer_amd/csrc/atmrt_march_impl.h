@@ -16,6 +16,8 @@ __shared__ double atmrt_dm_tables_lds[768];
 #ifndef ATMRT_OBJ_FN
 #define ATMRT_OBJ_FN __attribute__((noinline))
 #endif
+#include <cstdlib>
+#include <cstring>
 #include "atmrt_device.h"
 
 namespace atmrt {
@@ -62,11 +64,21 @@ constexpr int WAVE_CAND = 96;                // entries of a wavefront's list; m
 #define DRAIN_PRIO_MAX_BLOCKS 16384u
 #endif
 constexpr int DRAIN_PRIO_BAND = 512;
+// Test hook: ATMRT_MARCH_VARIANT=plain / small forces one variant for every launch, so that the random sweeps (small frames) can be
+// run over the kernel the full-size frames use, and the other way round.  Same results either way.
+static inline int march_variant_override() {
+  static const int v = [] {
+    const char* e = getenv("ATMRT_MARCH_VARIANT");
+    return !e ? 0 : !strcmp(e, "plain") ? 1 : !strcmp(e, "small") ? 2 : 0;
+  }();
+  return v;
+}
 // launches k_rect_march<MODE, CALC, CUBIC, DRAIN> over N rays / list entries, DRAIN by the grid size
 #define ATMRT_LAUNCH_MARCH(MODE, N, STREAM, ...)                                                                                       \
   do {                                                                                                                                 \
     const unsigned blocks_ = cdiv((size_t)(N), 256);                                                                                   \
-    if (blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                                                            \
+    const int override_ = march_variant_override();                                                                                    \
+    if (override_ ? override_ == 2 : blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                               \
       ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, true>), dim3(blocks_), dim3(256), 0, STREAM, \
                                                             __VA_ARGS__));                                                             \
     } else {                                                                                                                           \

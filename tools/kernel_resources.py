@@ -11,8 +11,14 @@ flags = [a for a in sys.argv[1:] if not a.endswith(".hip")]
 out = ""
 for unit in units:
     src = os.path.join(root, "atm-raytracer_amd", "csrc", unit)
-    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-c", src,
-           "-o", "/tmp/atmrt_k.o", "-Rpass-analysis=kernel-resource-usage"] + flags
+    # the per-unit flags of csrc/Makefile (MARCH_EXTRA, CALL_EXTRA): without them the numbers are not those of the shipped library
+    extra = []
+    if unit.startswith(("atmrt_march_", "atmrt_trace_")):
+        extra += ["-mllvm", "-disable-machine-licm"]
+    if unit.startswith("atmrt_trace_") or unit == "atmrt_kernels.hip":
+        extra += ["-mllvm", "-enable-ipra=0"]
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "-c", src,
+           "-o", "/tmp/atmrt_k.o", "-Rpass-analysis=kernel-resource-usage"] + extra + flags
     out += subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}
 for line in out.splitlines():

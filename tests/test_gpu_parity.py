@@ -420,6 +420,65 @@ def test_randomised_extremes(gpu_ctx, oracle_det, seed):
     assert np.array_equal(generators.draw_image(gpu_ctx, col, got["width"], got["height"]), oracle_det.draw_image(want, ocol))
 
 
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("ATMRT_HARNESS_SEEDS", "40"))))
+def test_randomised_harnesses(gpu_ctx, oracle_det, seed):
+    """The diagnostic entry points (output-atm, output-ray-paths, DirectionalCalc::coords_at_dist: src/atm_printer.rs:37-46,
+    ray_path.rs:65-103, directional_calc.rs:5-7) under random atmospheres, earth models, start heights, angles and steps:
+    temperature, pressure, n, dn/dh, every point of every path and every geodesic point equal to the oracle's, NaN as NaN."""
+    import ctypes as C
+    from atm_raytracer_amd import config, generators
+    from util import bits
+    rng = np.random.default_rng(900_000 + seed)
+    doc = {"earth_shape": EXTREME_EARTHS[int(rng.integers(len(EXTREME_EARTHS)))], "simulation_step": 50.0,
+           "wavelength": float(rng.uniform(300e-9, 1100e-9)), "output": {"width": 8, "height": 8}}
+    u = rng.uniform()
+    if u < 0.4:
+        n_knots = int(rng.integers(2, 9))
+        knots = np.sort(rng.uniform(-1000.0, 40_000.0, n_knots))
+        temps = 288.0 - 0.006 * knots + rng.uniform(-15.0, 15.0, n_knots)
+        doc["atmosphere"] = {"pressure": {"altitude": float(rng.uniform(-200.0, 3000.0)), "pressure": float(rng.uniform(300.0, 1100.0)) * 100.0},
+                             "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [[float(a), float(t)] for a, t in zip(knots, temps)]}}}
+    elif u < 0.8:
+        grads = [float(rng.choice([-0.0065, 0.0, 0.05, -0.05, -0.0342, float(rng.uniform(-0.02, 0.02)), 1e-9])) for _ in range(int(rng.integers(1, 7)))]
+        alts = np.sort(rng.uniform(-500.0, 50_000.0, len(grads) - 1))
+        doc["atmosphere"] = {"pressure": {"altitude": float(rng.uniform(-300.0, 5000.0)), "pressure": float(rng.uniform(200.0, 1100.0)) * 100.0},
+                             "temperature_fixed_point": {"altitude": float(rng.uniform(-300.0, 12000.0)), "temperature": float(rng.uniform(180.0, 330.0))},
+                             "first_temperature_function": {"Linear": {"gradient": grads[0]}},
+                             "next_functions": [{"altitude": float(a), "function": {"Linear": {"gradient": g}}} for a, g in zip(alts, grads[1:])]}
+    cfg = config.Config.from_dict(doc)
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(cfg.params)))
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(cfg.atmosphere)))
+    try:
+        # sampler: sorted runs (whole wavefronts inside one layer: the certified path) and a shuffled tail (per-lane layers)
+        alt = np.concatenate([np.sort(rng.uniform(-3000.0, 120_000.0, 1536)), rng.uniform(-3000.0, 400_000.0, 512)])
+        got = generators.atmosphere_sample(gpu_ctx, alt)
+        env = oracle_det.env(cfg.atmosphere, cfg.params.wavelength)
+        for k, f in (("temperature", oracle_det.temperature), ("pressure", oracle_det.pressure), ("n", oracle_det.n), ("dn_dh", oracle_det.dn)):
+            want = np.array([f(env, h) for h in alt], dtype=np.float64)
+            bad = np.flatnonzero(bits(got[k]) != bits(want))
+            assert bad.size == 0, (k, bad.size, alt[bad[:4]], got[k][bad[:4]], want[bad[:4]])
+        # integrator
+        ang = np.concatenate([rng.uniform(-89.0, 89.0, 6), rng.uniform(-2.0, 2.0, 6), [0.0, 90.0]])
+        h0 = float(rng.choice([rng.uniform(0.0, 50.0), rng.uniform(50.0, 12_000.0), rng.uniform(-300.0, 0.0)]))
+        step = float(rng.choice([rng.uniform(1.0, 50.0), rng.uniform(50.0, 2000.0), 100.0]))
+        straight = bool(rng.uniform() < 0.3)
+        n_steps = int(rng.integers(2, 400))
+        x, h = generators.ray_paths(gpu_ctx, h0, ang, step, n_steps, straight)
+        xo, ho = oracle_det.ray_paths(cfg.params, h0, ang, step, n_steps, straight, cfg.atmosphere)
+        assert np.array_equal(bits(x), bits(xo)) and np.array_equal(bits(h), bits(ho))
+        # geodesic points
+        d = np.concatenate([[0.0], rng.uniform(0.0, 500_000.0, 40), rng.uniform(0.0, 50.0, 8)])
+        lat0, lon0, dr = float(rng.uniform(-89.0, 89.0)), float(rng.uniform(-180.0, 180.0)), float(rng.uniform(-400.0, 800.0))
+        lat, lon = generators.coords_at_dist(gpu_ctx, lat0, lon0, dr, d)
+        want = oracle_det.coords_at_dist(cfg.params.earth, lat0, lon0, dr, d)
+        assert np.array_equal(bits(lat), bits(want[:, 0])) and np.array_equal(bits(lon), bits(want[:, 1]))
+    finally:
+        us = config.us76()
+        gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(us)))
+        d0 = config.Config.from_dict({"output": {"width": 8, "height": 8}})
+        gpu_ctx.check(gpu_ctx.lib.atmrt_set_params(gpu_ctx.handle, C.byref(d0.params)))
+
+
 WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
                "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [
                    [-500.0, 295.22010975963303], [16672.2152178729, 192.93808594359285], [16688.49864235047, 195.36762037322703],

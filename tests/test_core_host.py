@@ -155,3 +155,46 @@ def test_a_spline_that_overshoots_is_certified_only_where_it_is_tame(core):
     cfg = config.Config.from_dict({"atmosphere": tame, "output": {"width": 8, "height": 8}})
     c, _ = _certify(core, cfg.atmosphere)
     assert list(c["safe_lo"][1:6]) == [0.0, 1000.0, 1200.0, 5000.0, 11000.0] and list(c["safe_hi"][1:6]) == [1000.0, 1200.0, 5000.0, 11000.0, 20000.0]
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_certificates_of_random_atmospheres_hold_on_a_dense_sample(core, block):
+    """atm_certify's bounds are derived (end points of monotone quantities, stationary points of the cubic); ch_certify re-evaluates
+    T, p/T, Z and n at 4001 points of every certified interval.  50 random atmospheres per block — splines that overshoot, lapse
+    rates up to +-50 K/km, pressures from 200 to 1100 hPa: whatever carries a certificate must be far inside the shortcuts' range
+    (T >= 1 K, |Z - 1| <= 1/2, 1 <= n <= 2^8 + 1), and an interval never leaves its segment or the global altitude band."""
+    rng = np.random.default_rng(4242 + block)
+    n_certified = 0
+    for _ in range(50):
+        if rng.uniform() < 0.5:
+            n_knots = int(rng.integers(2, 9))
+            knots = np.sort(rng.uniform(-1000.0, 40_000.0, n_knots))
+            if np.min(np.diff(knots)) <= 0.0:
+                continue
+            temps = 288.0 - 0.006 * knots + rng.uniform(-15.0, 15.0, n_knots)
+            atm = {"pressure": {"altitude": float(rng.uniform(-200.0, 3000.0)), "pressure": float(rng.uniform(300.0, 1100.0)) * 100.0},
+                   "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [[float(a), float(t)] for a, t in zip(knots, temps)]}}}
+        else:
+            grads = [float(rng.choice([-0.0065, 0.0, 0.05, -0.05, -0.0342, float(rng.uniform(-0.02, 0.02)), 1e-9])) for _ in range(int(rng.integers(1, 7)))]
+            alts = np.sort(rng.uniform(-500.0, 50_000.0, len(grads) - 1))
+            atm = {"pressure": {"altitude": float(rng.uniform(-300.0, 5000.0)), "pressure": float(rng.uniform(200.0, 1100.0)) * 100.0},
+                   "temperature_fixed_point": {"altitude": float(rng.uniform(-300.0, 12000.0)), "temperature": float(rng.uniform(180.0, 330.0))},
+                   "first_temperature_function": {"Linear": {"gradient": grads[0]}},
+                   "next_functions": [{"altitude": float(a), "function": {"Linear": {"gradient": g}}} for a, g in zip(alts, grads[1:])]}
+        cfg = config.Config.from_dict({"atmosphere": atm, "output": {"width": 8, "height": 8}})
+        spherical = bool(rng.uniform() < 0.7)
+        radius = float(rng.choice([6371000.0, 3.0e6, 2.0e5])) if spherical else 0.0
+        c, band = _certify(core, cfg.atmosphere, spherical=spherical, radius=radius, wavelength=float(rng.uniform(300e-9, 1100e-9)))
+        n = len(c["from"])
+        for k in range(n):
+            if not c["safe_lo"][k] < c["safe_hi"][k]:
+                continue
+            n_certified += 1
+            # (the interval ends are found by bisection on the bounds: allow their rounding)
+            assert c["min_t"][k] >= 1.0 - 1e-9 and c["max_z_dev"][k] <= 0.5 + 1e-9 and 1.0 <= c["max_n"][k] <= 257.0, (atm, k)
+            assert band[0] <= c["safe_lo"][k] and c["safe_hi"][k] <= band[1]
+            if k > 0:
+                assert c["safe_lo"][k] >= c["from"][k]
+            if k + 1 < n:
+                assert c["safe_hi"][k] <= c["from"][k + 1]
+    assert n_certified > 50

@@ -269,7 +269,7 @@ def test_randomised_configurations(gpu_ctx, oracle_det, seed):
     wavelength, and — for a third of the seeds — a random atmosphere: 1-4 Linear layers with lapse, isothermal and inversion
     gradients, or a Spline temperature profile — and for a quarter random scene objects): every f64 field and every hit decision must match the oracle bit for bit.
     ATMRT_RANDOM_SEEDS widens the sweep and ATMRT_RANDOM_SEED_FIRST moves it (round 2: seed 4899 of a 6000-seed sweep found the
-    pathological atmosphere of test_pathological_atmosphere_is_still_bit_exact; seeds 0 .. 15999 pass on the final kernels)."""
+    pathological atmosphere of test_pathological_atmosphere_is_still_bit_exact; seeds 0 .. 59999 pass on the final kernels)."""
     rng = np.random.default_rng(1000 + seed)
     gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
     w, h = int(rng.integers(3, 70)), int(rng.integers(2, 40))

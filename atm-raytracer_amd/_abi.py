@@ -5,8 +5,6 @@ struct against the compiled library (atmrt_abi_sizeof).
 """
 import ctypes as C
 
-MAX_ATM_FUNCTIONS = 8
-MAX_SPLINE_POINTS = 32
 TEMP_LINEAR, TEMP_SPLINE = 0, 1
 SPLINE_BOUNDARY = {"Natural": 0, "Derivatives": 1, "SecondDerivatives": 2}
 
@@ -46,15 +44,36 @@ class Params(C.Structure):
 
 
 class TempFunction(C.Structure):
+    """atmrt_temp_function_t.  The spline points are borrowed pointers: set them with set_points(), which keeps the arrays alive
+    on the owning Atmosphere."""
     _fields_ = [("kind", C.c_int32), ("boundary", C.c_int32), ("altitude", C.c_double), ("gradient", C.c_double),
                 ("bc", C.c_double * 2), ("n_points", C.c_int32), ("_pad", C.c_int32),
-                ("point_altitude", C.c_double * MAX_SPLINE_POINTS), ("point_temperature", C.c_double * MAX_SPLINE_POINTS)]
+                ("point_altitude", C.POINTER(C.c_double)), ("point_temperature", C.POINTER(C.c_double))]
 
 
 class Atmosphere(C.Structure):
+    """atmrt_atmosphere_t: any number of temperature functions, any number of spline points (pointer + count, like the `Vec`s
+    of AtmosphereDef).  Build with Atmosphere.new(n): the function table and the point arrays are owned by the Python object."""
     _fields_ = [("pressure_altitude", C.c_double), ("pressure", C.c_double), ("temperature_altitude", C.c_double),
                 ("temperature", C.c_double), ("has_temperature_fixed_point", C.c_int32), ("n_functions", C.c_int32),
-                ("functions", TempFunction * MAX_ATM_FUNCTIONS)]
+                ("functions", C.POINTER(TempFunction))]
+
+    @classmethod
+    def new(cls, n_functions):
+        a = cls()
+        a._table = (TempFunction * max(1, n_functions))()
+        a._points = []
+        a.functions = C.cast(a._table, C.POINTER(TempFunction))
+        a.n_functions = n_functions
+        return a
+
+    def set_points(self, k, altitudes, temperatures):
+        n = len(altitudes)
+        xa, ya = (C.c_double * n)(*[float(v) for v in altitudes]), (C.c_double * n)(*[float(v) for v in temperatures])
+        self._points.append((xa, ya))
+        fn = self.functions[k]
+        fn.n_points = n
+        fn.point_altitude, fn.point_temperature = C.cast(xa, C.POINTER(C.c_double)), C.cast(ya, C.POINTER(C.c_double))
 
 
 class Object(C.Structure):
@@ -117,6 +136,17 @@ def numpy_to_result(res):
     r.color_tag = ptr("color_tag", np.uint32, C.c_uint32)
     r.ray_steps = int(res["ray_steps"])
     return r, keep
+
+
+class CommTimings(C.Structure):
+    _fields_ = [("gather_ms", C.c_double), ("assemble_ms", C.c_double), ("tile_ms_max", C.c_double), ("tile_ms_min", C.c_double),
+                ("bytes_per_rank", C.c_uint64), ("world", C.c_int32), ("route", C.c_int32), ("collectives", C.c_int32), ("_pad", C.c_int32)]
+
+
+ROUTES = {0: "none", 1: "rccl", 2: "peer", 3: "external", 4: "host"}
+COMM_ID_BYTES = 128
+# atmrt_all_gather_fn(user, send_host, recv_host, bytes_per_rank) -> int
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class Timings(C.Structure):

@@ -20,13 +20,14 @@ class AtmrtError(RuntimeError):
 
 
 def source_hash():
-    """sha256 over the sources libatmrt.so is built from (csrc/*.h, csrc/*.hip, include/atmrt.h): profile summaries under
+    """sha256 over the sources libatmrt.so is built from (csrc/*.h, csrc/*.hip, csrc/Makefile, include/atmrt.h): profile summaries under
     profiles/ carry the hash of the sources their counters were collected with, and bench.py only quotes counters whose hash
     matches the tree it runs from."""
     import glob
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
+    files.append(os.path.join(CSRC, "Makefile"))  # the per-unit code generation flags live there
     files.append(os.path.join(os.path.dirname(CSRC), "..", "include", "atmrt.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -92,12 +93,22 @@ def load():
         "atmrt_math_probe": (C.c_int, [vp, i32, sz, vp, vp, vp, vp]),
         "atmrt_result_encode_bincode": (C.c_int, [C.POINTER(_abi.Result), i32, vp, sz, C.POINTER(sz)]),
         "atmrt_result_decode_bincode": (C.c_int, [vp, sz, i32, C.POINTER(_abi.Result), C.POINTER(sz)]),
+        # several GPUs (include/atmrt.h)
+        "atmrt_comm_unique_id": (C.c_int, [vp]),
+        "atmrt_ctx_comm_init_rank": (C.c_int, [vp, vp, i32, i32]),
+        "atmrt_ctx_comm_init_external": (C.c_int, [vp, i32, i32, _abi.ALL_GATHER_FN, vp]),
+        "atmrt_ctx_create_multi": (C.c_int, [C.POINTER(vp), C.POINTER(i32), i32]),
+        "atmrt_ctx_device_count": (C.c_int, [vp]),
+        "atmrt_generate_image_device": (C.c_int, [vp, C.POINTER(_abi.DevicePlanes), C.POINTER(C.c_uint64), pd]),
+        "atmrt_image_hits_device": (C.c_int, [vp, C.POINTER(_abi.DeviceHits), C.POINTER(C.c_uint64)]),
+        "atmrt_draw_image_gathered_device": (C.c_int, [vp, C.POINTER(_abi.Coloring), C.POINTER(vp)]),
+        "atmrt_last_comm_timings": (C.c_int, [vp, C.POINTER(_abi.CommTimings)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if L.atmrt_abi_version() != 3:
+    if L.atmrt_abi_version() != 4:
         raise ImportError("libatmrt.so ABI version mismatch")
     _lib = L
     return L
@@ -109,4 +120,6 @@ EXPORTED = ["atmrt_abi_version", "atmrt_ctx_create", "atmrt_ctx_destroy", "atmrt
             "atmrt_result_free", "atmrt_generate_device", "atmrt_last_hits_device", "atmrt_last_timings", "atmrt_last_stats", "atmrt_debug_fail_next_frame", "atmrt_coloring_from_conf", "atmrt_draw_image",
             "atmrt_draw_image_device", "atmrt_ray_paths", "atmrt_atmosphere_sample",
             "atmrt_coords_at_dist", "atmrt_math_probe", "atmrt_result_encode_bincode",
-            "atmrt_result_decode_bincode"]
+            "atmrt_result_decode_bincode", "atmrt_comm_unique_id", "atmrt_ctx_comm_init_rank", "atmrt_ctx_comm_init_external",
+            "atmrt_ctx_create_multi", "atmrt_ctx_device_count", "atmrt_generate_image_device", "atmrt_image_hits_device",
+            "atmrt_draw_image_gathered_device", "atmrt_last_comm_timings"]

@@ -65,19 +65,19 @@ def _earth(node):  # EarthModel, earth_model/mod.rs:18-28; default Spherical{637
 
 def us76():
     """AtmosphereDef::us_76 (params.rs:453)."""
-    a = _abi.Atmosphere()
     alts = [0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0]
     grads = [-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002]
+    a = _abi.Atmosphere.new(len(alts))
     a.pressure_altitude, a.pressure = 0.0, 101325.0
     a.temperature_altitude, a.temperature, a.has_temperature_fixed_point = 0.0, 288.15, 1
-    a.n_functions = len(alts)
     for k, (h, g) in enumerate(zip(alts, grads)):
         a.functions[k].kind, a.functions[k].altitude, a.functions[k].gradient = _abi.TEMP_LINEAR, h, g
     return a
 
 
-def _temperature_function(node, fn):
-    """`Linear{gradient}` or `Spline{boundary_condition, points}` (reference README.md:290-316) into an atmrt_temp_function_t."""
+def _temperature_function(node, a, index):
+    """`Linear{gradient}` or `Spline{boundary_condition, points}` (reference README.md:290-316) into function `index` of `a`."""
+    fn = a.functions[index]
     if isinstance(node, dict) and len(node) == 1:
         (k, v), = node.items()
         if k == "Linear":
@@ -96,11 +96,9 @@ def _temperature_function(node, fn):
                     raise ConfigError(f"unknown boundary_condition {bc!r}")
                 fn.boundary, fn.bc[0], fn.bc[1] = _abi.SPLINE_BOUNDARY[bk], float(bv[0]), float(bv[1])
             pts = v["points"]
-            if not 2 <= len(pts) <= _abi.MAX_SPLINE_POINTS:
-                raise ConfigError(f"a Spline needs 2..{_abi.MAX_SPLINE_POINTS} points")
-            fn.n_points = len(pts)
-            for i, (alt, temp) in enumerate(pts):
-                fn.point_altitude[i], fn.point_temperature[i] = float(alt), float(temp)
+            if len(pts) < 2:
+                raise ConfigError("a Spline needs at least 2 points")
+            a.set_points(index, [p[0] for p in pts], [p[1] for p in pts])
             return
     raise ConfigError(f"unknown temperature function {node!r}")
 
@@ -108,16 +106,13 @@ def _temperature_function(node, fn):
 def _atmosphere(node):  # AtmosphereDef schema, reference README.md:283-323
     if node is None:
         return us76()
-    a = _abi.Atmosphere()
     pr = node["pressure"]
-    a.pressure_altitude, a.pressure = float(pr["altitude"]), float(pr["pressure"])
     functions = [(0.0, node["first_temperature_function"])] + [(float(nf["altitude"]), nf["function"]) for nf in node.get("next_functions", []) or []]
-    if len(functions) > _abi.MAX_ATM_FUNCTIONS:
-        raise ConfigError("too many temperature functions")
-    a.n_functions = len(functions)
+    a = _abi.Atmosphere.new(len(functions))
+    a.pressure_altitude, a.pressure = float(pr["altitude"]), float(pr["pressure"])
     for k, (h, f) in enumerate(functions):
         a.functions[k].altitude = h
-        _temperature_function(f, a.functions[k])
+        _temperature_function(f, a, k)
     fixed = node.get("temperature_fixed_point")
     has_spline = any(a.functions[k].kind == _abi.TEMP_SPLINE for k in range(a.n_functions))
     if fixed is not None:

@@ -15,8 +15,10 @@
 #include <utility>
 #include <vector>
 
+#include "atmrt_ctx.h"
 #include "atmrt_hostmem.h"
 #include "atmrt_kernels.h"
+#include "atmrt_multi.h"
 #include "atmrt_render.h"
 #include "atmrt_tiff.h"
 
@@ -27,114 +29,7 @@ namespace {
 std::mutex g_err_mutex;
 std::string g_create_error = "";
 
-struct HostTile {
-  int n_lat = 0, n_lon = 0;
-  std::vector<int16_t> posts; // [n_lat][n_lon]
-};
-
-// grow-only device buffer
-struct DevBuf {
-  void* ptr = nullptr;
-  size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&ptr, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    cap = 0;
-  }
-  template <class T>
-  T* as() const { return static_cast<T*>(ptr); }
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), cap(o.cap) { o.ptr = nullptr, o.cap = 0; }
-  DevBuf& operator=(DevBuf&& o) noexcept { // std::swap of two buffers (run_interpolating keeps the lattice result that way)
-    if (this != &o) {
-      release();
-      ptr = o.ptr, cap = o.cap;
-      o.ptr = nullptr, o.cap = 0;
-    }
-    return *this;
-  }
-  ~DevBuf() { release(); } // atmrt_ctx_destroy makes the context's device current before the context (and its buffers) goes
-};
-
 } // namespace
-
-struct atmrt_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr, stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-  hipEvent_t ev[10] = {};
-  hipEvent_t ev_seg[FAST_SEGMENTS] = {}; // a path segment is integrated (stream2) -> its intersect scan may start
-  hipEvent_t ev_scan[2 * FAST_SEGMENTS] = {}; // begin / end of every scan segment (after its wait), for intersect_ms
-  int scan_segments = 0;                       // segments of the last pipelined frame (0: ev[4]..ev[5] time the scan)
-  atmrt_timings_t timings{};
-  atmrt_frame_stats_t stats{};
-  bool inject_failure = false; // atmrt_debug_fail_next_frame
-  std::string error;
-
-  // terrain (Terrain, terrain/mod.rs:55-57): tiles keyed by integer degrees
-  std::map<std::pair<int, int>, HostTile> tiles;
-  bool terrain_dirty = true;
-  DevBuf d_posts, d_tiles, d_cells;
-  TerrainView tv{};
-
-  bool have_params = false;
-  atmrt_params_t params{};
-  atmrt_atmosphere_t atm_def{};
-  AtmTable atm{};
-  Earth earth{};
-  Pinhole pinhole{};
-  std::vector<double> xs;
-  int n_t = 0, n_path_cap = 0;
-  bool xs_dirty = true;
-
-  // last generated frame (for atmrt_draw_image)
-  bool last_valid = false, last_packed = false;
-  size_t last_npx = 0;
-  double last_alpha = 1.0;
-  DensePlanes last_dense{};
-  PackedHits last_hits{};
-  const uint64_t* last_offset = nullptr;
-  uint64_t last_nhits = 0;
-
-  std::vector<ObjectDev> objects;      // host image of the device table (altitude kind in _pad until k_resolve)
-  std::vector<uint8_t> textures;       // RGBA8 pool
-  bool objects_dirty = true;
-
-  // workspace
-  DevBuf d_xs, d_alt, d_colcalc, d_prof, d_pelev, d_plen, d_npath, d_hit_step, d_hit_offset, d_scan_tmp, d_counters,
-      d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
-      d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
-      d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev, d_step_prop,
-      d_blend_arena, d_object_rays, d_col_lo, d_col_hi, d_traced;
-
-  int fail(int code, const char* fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    error = buf;
-    return code;
-  }
-};
-
-#define HIP_TRY(ctx, expr)                                                                               \
-  do {                                                                                                   \
-    hipError_t e_ = (expr);                                                                              \
-    if (e_ != hipSuccess) return (ctx)->fail(ATMRT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // DTED (MIL-PRF-89020B) — replaces crate dted 0.2's read_dted / read_dted_header (terrain/mod.rs:24,86)
@@ -229,6 +124,8 @@ extern "C" size_t atmrt_abi_sizeof(int which) {
     case 9: return sizeof(atmrt_timings_t);
     case 10: return sizeof(atmrt_coloring_t);
     case 11: return sizeof(atmrt_device_hits_t);
+    case 12: return sizeof(atmrt_comm_timings_t);
+    case 13: return sizeof(atmrt_temp_function_t);
     default: return 0;
   }
 }
@@ -247,7 +144,11 @@ static int create_fail(int code, const std::string& msg) {
   return code;
 }
 
-extern "C" int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal) {
+int atmrt::api_create_fail(int code, const std::string& msg) { return create_fail(code, msg); }
+
+extern "C" int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal) { return api_create_plain(out, device_ordinal); }
+
+int atmrt::api_create_plain(atmrt_ctx** out, int device_ordinal) {
   if (!out) return create_fail(ATMRT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   int n = 0;
@@ -293,14 +194,20 @@ extern "C" int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal) {
     }
   }
   atmrt_params_default(&c->params);
-  atmrt_atmosphere_us76(&c->atm_def);
+  {
+    atmrt_atmosphere_t us;
+    atmrt_atmosphere_us76(&us);
+    c->atm_def.assign(us);
+  }
   *out = c;
   return ATMRT_OK;
 }
 
 extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
   if (!c) return;
+  if (c->multi) multi_destroy(c); // the children first, each on its own worker thread
   (void)hipSetDevice(c->device);
+  if (c->comm) comm_destroy(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   for (DevBuf* b : {&c->d_posts, &c->d_tiles, &c->d_cells, &c->d_xs, &c->d_alt, &c->d_colcalc, &c->d_prof, &c->d_pelev,
@@ -330,8 +237,8 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int atmrt_terrain_clear(atmrt_ctx* c) {
   if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
-  c->tiles.clear();
-  c->terrain_dirty = true;
+  c->terrain->tiles.clear();
+  c->terrain->generation++;
   return ATMRT_OK;
 }
 
@@ -342,11 +249,11 @@ extern "C" int atmrt_terrain_add_tile(atmrt_ctx* c, int32_t lat0, int32_t lon0, 
     return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "bad tile shape %d x %d", n_lat, n_lon);
   if (lat0 < -90 || lat0 > 89 || lon0 < -360 || lon0 > 359)
     return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "tile origin (%d, %d) out of range", lat0, lon0);
-  HostTile& t = c->tiles[{lat0, lon0}]; // HashMap::insert replaces (terrain/mod.rs:93-96)
+  HostTile& t = c->terrain->tiles[{lat0, lon0}]; // HashMap::insert replaces (terrain/mod.rs:93-96)
   t.n_lat = n_lat;
   t.n_lon = n_lon;
   t.posts.assign(posts, posts + (size_t)n_lat * n_lon);
-  c->terrain_dirty = true;
+  c->terrain->generation++;
   return ATMRT_OK;
 }
 
@@ -370,43 +277,44 @@ extern "C" int atmrt_terrain_load_dir(atmrt_ctx* c, const char* path, int32_t* n
       t = HostTile{};
       if (atmrt_tiff::read_dem(full, 3601, t.posts, why)) {
         t.n_lat = t.n_lon = 3601; // geotiff.rs:70-71: a 3600-interval grid per degree, file row = latitude index
-        c->tiles[{lat0, lon0}] = std::move(t);
+        c->terrain->tiles[{lat0, lon0}] = std::move(t);
       } else {
-        c->tiles.erase({lat0, lon0});
+        c->terrain->tiles.erase({lat0, lon0});
       }
       files++;
       continue;
     }
     if (rc) {
       closedir(d);
-      c->terrain_dirty = true; // tiles read before the bad file are in the map: the mosaic must be rebuilt to match it
+      c->terrain->generation++; // tiles read before the bad file are in the map: the mosaic must be rebuilt to match it
       return c->fail(rc, "%s", msg.c_str());
     }
-    c->tiles[{lat0, lon0}] = std::move(t);
+    c->terrain->tiles[{lat0, lon0}] = std::move(t);
     files++;
   }
   closedir(d);
-  c->terrain_dirty = true;
+  c->terrain->generation++;
   if (n_files) *n_files = files;
   return ATMRT_OK;
 }
 
 // Upload the tile mosaic: all posts back to back + a dense (lat, lon) cell -> tile table.
 static int upload_terrain(atmrt_ctx* c) {
-  if (!c->terrain_dirty) return ATMRT_OK;
+  const TileStore& store = *c->terrain; // shared by the devices of a multi-device context: read-only while a frame is prepared
+  if (c->terrain_uploaded == store.generation) return ATMRT_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   TerrainView tv{};
-  if (c->tiles.empty()) {
+  if (store.tiles.empty()) {
     tv.lat_min = tv.lon_min = 0;
     tv.n_cells_lat = tv.n_cells_lon = 0;
     tv.skip_above = 1.0; // no tiles: every lookup is 0 m
     c->tv = tv;
-    c->terrain_dirty = false;
+    c->terrain_uploaded = store.generation;
     return ATMRT_OK;
   }
   int lat_min = 1 << 30, lat_max = -(1 << 30), lon_min = 1 << 30, lon_max = -(1 << 30);
   size_t total = 0;
-  for (auto& kv : c->tiles) {
+  for (auto& kv : store.tiles) {
     lat_min = std::min(lat_min, kv.first.first);
     lat_max = std::max(lat_max, kv.first.first);
     lon_min = std::min(lon_min, kv.first.second);
@@ -418,7 +326,7 @@ static int upload_terrain(atmrt_ctx* c) {
   std::vector<TileDesc> descs;
   std::vector<int16_t> mosaic;
   mosaic.reserve(total + 8);
-  for (auto& kv : c->tiles) {
+  for (auto& kv : store.tiles) {
     TileDesc td;
     td.offset = (int64_t)mosaic.size();
     td.n_lat = kv.second.n_lat;
@@ -444,7 +352,7 @@ static int upload_terrain(atmrt_ctx* c) {
   for (int16_t v : mosaic) top = std::max(top, v);
   tv.skip_above = (double)top + 1.0;
   c->tv = tv;
-  c->terrain_dirty = false;
+  c->terrain_uploaded = store.generation;
   return ATMRT_OK;
 }
 
@@ -475,6 +383,17 @@ extern "C" void atmrt_params_default(atmrt_params_t* p) { // Config::default, pa
 extern "C" void atmrt_atmosphere_us76(atmrt_atmosphere_t* a) {
   static const double alt[7] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0};
   static const double lapse[7] = {-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002};
+  static const struct Table {
+    atmrt_temp_function_t fn[7];
+    Table() {
+      memset(fn, 0, sizeof fn);
+      for (int k = 0; k < 7; k++) {
+        fn[k].kind = ATMRT_TEMP_LINEAR;
+        fn[k].altitude = alt[k];
+        fn[k].gradient = lapse[k];
+      }
+    }
+  } table;
   memset(a, 0, sizeof *a);
   a->pressure_altitude = 0.0;
   a->pressure = 101325.0;
@@ -482,26 +401,22 @@ extern "C" void atmrt_atmosphere_us76(atmrt_atmosphere_t* a) {
   a->temperature = 288.15;
   a->has_temperature_fixed_point = 1;
   a->n_functions = 7;
-  for (int k = 0; k < 7; k++) {
-    a->functions[k].kind = ATMRT_TEMP_LINEAR;
-    a->functions[k].altitude = alt[k];
-    a->functions[k].gradient = lapse[k];
-  }
+  a->functions = table.fn; // library-owned, immutable
 }
 
 extern "C" int atmrt_set_atmosphere(atmrt_ctx* c, const atmrt_atmosphere_t* a) {
   if (!c || !a) return ATMRT_ERR_INVALID_ARGUMENT;
-  AtmTable t;
+  AtmTableBuf t;
   static const char* why[] = {"", "bad function count or kind", "function altitudes must increase",
-                              "no temperature anchor: give temperature_fixed_point or a Spline", "bad spline points",
-                              "more than 64 temperature segments"};
+                              "no temperature anchor: give temperature_fixed_point or a Spline", "bad spline points"};
   int rc = atm_compile(*a, c->params.wavelength, t);
-  if (rc) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere definition: %s", why[-rc <= 5 ? -rc : 1]);
+  if (rc) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere definition: %s", why[-rc <= 4 ? -rc : 1]);
   if (!(a->pressure > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "the pressure fixed point must be positive");
   // Nothing derived is validated: a profile that runs through 0 K, or whose hydrostatic pressure overflows, is marched like any
   // other (NaN and inf propagate as they do in the reference's f64 arithmetic); such segments get no certificate (atm_certify)
   // and are evaluated with IEEE operations.  Until round 2 they were rejected here.
-  c->atm_def = *a;
+  c->atm_def.assign(*a);
+  if (c->multi) return multi_forward(c, [a](atmrt_ctx* k) { return atmrt_set_atmosphere(k, a); });
   return ATMRT_OK;
 }
 
@@ -529,9 +444,13 @@ extern "C" int atmrt_set_params(atmrt_ctx* c, const atmrt_params_t* p) {
   // distances handed to SphericalCalc are sums of steps and interpolation points inside a step: 0 or >= ~1e-17 step
   if (e.calc_radius >= 1.0e-30 && e.calc_radius <= 1.0e30 && p->simulation_step >= 1.0e-10 && p->frame.max_distance <= 1.0e30)
     e.flat_dirs |= EARTH_FAST_DIV;
+  if ((c->comm || c->multi) && !(p->col_begin == 0 && p->col_end == 0))
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "col_begin / col_end must be 0 on a context that shares its frame with other ranks or "
+                                               "devices: the library assigns the pixel-column tiles itself");
   c->params = *p;
   c->earth = e;
   c->have_params = true;
+  if (c->multi) return multi_forward(c, [p](atmrt_ctx* k) { return atmrt_set_params(k, p); });
   return ATMRT_OK;
 }
 
@@ -572,6 +491,7 @@ extern "C" int atmrt_objects_set(atmrt_ctx* c, const atmrt_object_t* objects, si
   c->objects.swap(objs);
   c->textures.swap(pool);
   c->objects_dirty = true;
+  if (c->multi) return multi_forward(c, [objects, n](atmrt_ctx* k) { return atmrt_objects_set(k, objects, n); });
   return ATMRT_OK;
 }
 
@@ -584,8 +504,8 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   int rc = upload_terrain(c);
   if (rc) return rc;
   const atmrt_params_t& p = c->params;
-  if (atm_compile(c->atm_def, p.wavelength, c->atm)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere");
-  atm_certify(c->atm, c->earth.spherical != 0, c->earth.shape_radius, p.simulation_step);
+  if (atm_compile(c->atm_def.pod, p.wavelength, c->atm)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere");
+  atm_certify(c->atm.table(), c->earth.spherical != 0, c->earth.shape_radius, p.simulation_step);
   pinhole_init(p, c->pinhole);
   if (c->xs_dirty) {
     // distance table by repeated addition, exactly like `distance += step` (utils.rs:191-196) and the
@@ -611,8 +531,8 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   Frame f{};
   f.p = p;
   f.earth = c->earth;
-  HIP_TRY(c, c->d_atm.reserve(sizeof(AtmTable)));
-  HIP_TRY(c, hipMemcpy(c->d_atm.ptr, &c->atm, sizeof(AtmTable), hipMemcpyHostToDevice));
+  HIP_TRY(c, c->d_atm.reserve(c->atm.bytes()));
+  HIP_TRY(c, hipMemcpy(c->d_atm.ptr, &c->atm.table(), c->atm.bytes(), hipMemcpyHostToDevice));
   f.atm = c->d_atm.as<AtmTable>();
   f.ph = c->pinhole;
   f.tv = c->tv;
@@ -634,12 +554,18 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   f.n_objects = (int32_t)c->objects.size();
   f.n_t = c->n_t;
   f.n_path_cap = c->n_path_cap;
-  f.c0 = (p.col_begin == 0 && p.col_end == 0) ? 0 : p.col_begin;
-  f.wl = (p.col_begin == 0 && p.col_end == 0) ? p.width : p.col_end - p.col_begin;
+  {
+    int c0 = (p.col_begin == 0 && p.col_end == 0) ? 0 : p.col_begin;
+    int c1 = (p.col_begin == 0 && p.col_end == 0) ? p.width : p.col_end;
+    if (c->comm) comm_columns(c, p.width, &c0, &c1); // a rank / device of a shared frame: the library's own pixel-column tile
+    if (c1 <= c0) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "image width %u leaves this rank without a pixel column", p.width);
+    f.c0 = c0;
+    f.wl = c1 - c0;
+  }
   f.h = p.height;
   f.opaque = (p.terrain_alpha == 1.0 && c->objects.empty()) ? 1 : 0;
   f.lattice = 0;
-  f.atm_cubic = atm_has_cubic(c->atm) ? 1 : 0;
+  f.atm_cubic = atm_has_cubic(c->atm.table()) ? 1 : 0;
   f.di0 = f.ei0 = 0;
   f.dir_step = f.elev_step = 0.0;
   *out = f;
@@ -1075,6 +1001,9 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->last_valid = true;
   c->last_packed = want_packed || !f.opaque || f.p.generator == ATMRT_GEN_INTERPOLATING_RECTILINEAR;
   c->last_npx = (size_t)f.wl * f.h;
+  c->last_wl = f.wl;
+  c->last_h = f.h;
+  c->last_c0 = f.c0;
   c->last_alpha = f.p.terrain_alpha;
   c->last_dense = dense;
   c->last_hits = packed;
@@ -1177,9 +1106,32 @@ extern "C" void atmrt_result_free(atmrt_result_t* r) {
   memset(r, 0, sizeof *r);
 }
 
+// One frame of this context's tile, everything left in HBM (shared by atmrt_generate_device and the multi-device paths).
+int atmrt::api_generate_tile(atmrt_ctx* c, const DensePlanes* dense_in, bool want_packed, uint64_t* n_hits, uint64_t* ray_steps,
+                             double* device_ms) {
+  Frame f;
+  int rc = prepare_frame(c, &f);
+  if (rc) return rc;
+  Workspace ws{};
+  if ((rc = prepare_workspace(c, f, &ws))) return rc;
+  DensePlanes dense;
+  if (dense_in) {
+    dense = *dense_in;
+  } else {
+    const size_t npx = (size_t)f.wl * f.h;
+    HIP_TRY(c, c->d_dense.reserve(dense_bytes(npx)));
+    dense = carve_dense(c->d_dense.ptr, npx);
+  }
+  uint64_t nh = 0;
+  rc = run_generator(c, f, ws, dense, want_packed, nullptr, &nh, ray_steps, device_ms);
+  if (n_hits) *n_hits = nh;
+  return rc;
+}
+
 extern "C" int atmrt_generate(atmrt_ctx* c, atmrt_result_t* out) {
   if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
   memset(out, 0, sizeof *out);
+  if (c->multi) return multi_generate(c, out); // every device its pixel-column tile, straight into the one [H][W] block
   Frame f;
   int rc = prepare_frame(c, &f);
   if (rc) return rc;
@@ -1224,6 +1176,7 @@ extern "C" int atmrt_generate(atmrt_ctx* c, atmrt_result_t* out) {
 extern "C" int atmrt_generate_device(atmrt_ctx* c, const atmrt_device_planes_t* planes, uint64_t* ray_steps,
                                      double* device_ms) {
   if (!c || !planes) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return c->fail(ATMRT_ERR_STATE, "a multi-device context leaves its frame in HBM through atmrt_generate_image_device");
   if (!planes->azimuth || !planes->elevation_angle || !planes->hit_count || !planes->lat || !planes->lon ||
       !planes->distance || !planes->elevation || !planes->path_length || !planes->normal)
     return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "every plane pointer must be a device allocation");
@@ -1248,6 +1201,7 @@ extern "C" int atmrt_generate_device(atmrt_ctx* c, const atmrt_device_planes_t* 
 
 extern "C" int atmrt_last_hits_device(atmrt_ctx* c, const atmrt_device_hits_t* dst, uint64_t* n_hits) {
   if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return c->fail(ATMRT_ERR_STATE, "a multi-device context hands its lists over through atmrt_image_hits_device");
   if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_last_hits_device needs a frame: call atmrt_generate_device first");
   if (!c->last_packed)
     return c->fail(ATMRT_ERR_STATE, "the last frame holds first-hit planes only (opaque scene through atmrt_generate_device): "
@@ -1280,18 +1234,21 @@ extern "C" int atmrt_last_hits_device(atmrt_ctx* c, const atmrt_device_hits_t* d
 
 extern "C" int atmrt_last_timings(atmrt_ctx* c, atmrt_timings_t* out) {
   if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return multi_last_timings(c, out);
   *out = c->timings;
   return ATMRT_OK;
 }
 
 extern "C" int atmrt_debug_fail_next_frame(atmrt_ctx* c) {
   if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return atmrt_debug_fail_next_frame(multi_child(c, multi_size(c) - 1));
   c->inject_failure = true;
   return ATMRT_OK;
 }
 
 extern "C" int atmrt_last_stats(atmrt_ctx* c, atmrt_frame_stats_t* out) {
   if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return multi_last_stats(c, out);
   *out = c->stats;
   return ATMRT_OK;
 }
@@ -1312,6 +1269,7 @@ extern "C" int atmrt_coloring_from_conf(const atmrt_params_t* params, int32_t ki
 
 extern "C" int atmrt_draw_image_device(atmrt_ctx* c, const atmrt_coloring_t* coloring, uint8_t* rgb_device) {
   if (!c || !coloring || !rgb_device) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return c->fail(ATMRT_ERR_STATE, "a multi-device context draws through atmrt_draw_image (host image) or atmrt_draw_image_gathered_device");
   if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_draw_image needs a frame: call atmrt_generate first");
   if (coloring->kind != ATMRT_COLORING_SIMPLE && coloring->kind != ATMRT_COLORING_SHADING)
     return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "unknown coloring kind %d", coloring->kind);
@@ -1326,6 +1284,7 @@ extern "C" int atmrt_draw_image_device(atmrt_ctx* c, const atmrt_coloring_t* col
 
 extern "C" int atmrt_draw_image(atmrt_ctx* c, const atmrt_coloring_t* coloring, uint8_t* rgb) {
   if (!c || !coloring || !rgb) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (c->multi) return multi_draw_image(c, coloring, rgb);
   if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_draw_image needs a frame: call atmrt_generate first");
   HIP_TRY(c, hipSetDevice(c->device)); // the staging buffer must live on this context's device
   HIP_TRY(c, c->d_io.reserve(3 * c->last_npx + 256));
@@ -1338,6 +1297,17 @@ extern "C" int atmrt_draw_image(atmrt_ctx* c, const atmrt_coloring_t* coloring, 
 // ---------------------------------------------------------------------------------------------
 // harnesses: host arrays in, host arrays out (staged through one device buffer)
 // ---------------------------------------------------------------------------------------------
+// the diagnostic entry points of a multi-device context run on its first device
+#define FORWARD_TO_FIRST_DEVICE(c, call) \
+  do {                                   \
+    if ((c) && (c)->multi) {             \
+      atmrt_ctx* k_ = multi_child((c), 0); \
+      int rc_ = (call);                  \
+      if (rc_) (c)->error = k_->error;   \
+      return rc_;                        \
+    }                                    \
+  } while (0)
+
 static int harness_frame(atmrt_ctx* c, Frame* f) {
   if (!c->have_params) {
     atmrt_params_t p;
@@ -1351,6 +1321,7 @@ static int harness_frame(atmrt_ctx* c, Frame* f) {
 extern "C" int atmrt_terrain_get_elev(atmrt_ctx* c, size_t n, const double* lat, const double* lon, double* elev,
                                       uint8_t* valid) {
   if (!c || (n && (!lat || !lon || !elev || !valid))) return ATMRT_ERR_INVALID_ARGUMENT;
+  FORWARD_TO_FIRST_DEVICE(c, atmrt_terrain_get_elev(k_, n, lat, lon, elev, valid));
   Frame f;
   int rc = harness_frame(c, &f);
   if (rc) return rc;
@@ -1373,6 +1344,7 @@ extern "C" int atmrt_terrain_get_elev(atmrt_ctx* c, size_t n, const double* lat,
 extern "C" int atmrt_ray_paths(atmrt_ctx* c, double h0, size_t n_angles, const double* angles_deg, int32_t straight,
                                double step, size_t n_steps, double* x, double* h) {
   if (!c || (n_angles && (!angles_deg || !x || !h))) return ATMRT_ERR_INVALID_ARGUMENT;
+  FORWARD_TO_FIRST_DEVICE(c, atmrt_ray_paths(k_, h0, n_angles, angles_deg, straight, step, n_steps, x, h));
   if (!(step > 0.0)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "step must be positive"); // ray_path.rs:53
   if (n_steps > 50000000) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "too many steps");
   Frame f;
@@ -1396,6 +1368,7 @@ extern "C" int atmrt_ray_paths(atmrt_ctx* c, double h0, size_t n_angles, const d
 extern "C" int atmrt_atmosphere_sample(atmrt_ctx* c, size_t n, const double* altitude, double* temperature,
                                        double* pressure, double* n_index, double* dn_dh) {
   if (!c || (n && (!altitude || !temperature || !pressure || !n_index || !dn_dh))) return ATMRT_ERR_INVALID_ARGUMENT;
+  FORWARD_TO_FIRST_DEVICE(c, atmrt_atmosphere_sample(k_, n, altitude, temperature, pressure, n_index, dn_dh));
   Frame f;
   int rc = harness_frame(c, &f);
   if (rc) return rc;
@@ -1416,6 +1389,7 @@ extern "C" int atmrt_atmosphere_sample(atmrt_ctx* c, size_t n, const double* alt
 extern "C" int atmrt_coords_at_dist(atmrt_ctx* c, double lat0, double lon0, double dir_deg, size_t n,
                                     const double* dist, double* lat, double* lon) {
   if (!c || (n && (!dist || !lat || !lon))) return ATMRT_ERR_INVALID_ARGUMENT;
+  FORWARD_TO_FIRST_DEVICE(c, atmrt_coords_at_dist(k_, lat0, lon0, dir_deg, n, dist, lat, lon));
   Frame f;
   int rc = harness_frame(c, &f);
   if (rc) return rc;
@@ -1433,6 +1407,7 @@ extern "C" int atmrt_coords_at_dist(atmrt_ctx* c, double lat0, double lon0, doub
 
 extern "C" int atmrt_math_probe(atmrt_ctx* c, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1) {
   if (!c || (n && (!a || !out0)) || op < 0 || op > ATMRT_PROBE_DIV3) return ATMRT_ERR_INVALID_ARGUMENT;
+  FORWARD_TO_FIRST_DEVICE(c, atmrt_math_probe(k_, op, n, a, b, out0, out1));
   if (!n) return ATMRT_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->d_io.reserve(4 * n * 8));

@@ -9,6 +9,8 @@
 
 #include <stdint.h>
 
+#include <vector>
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ATMRT_HD __host__ __device__ inline __attribute__((always_inline))
@@ -45,33 +47,61 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // interval (plus linear continuations outside its knots).  In a segment T(h) = tb + c1 dh + c2 dh^2 + c3 dh^3 with
 // dh = h - hb.  Linear segments (cubic == 0) use the closed-form hydrostatic pressure, cubic ones a 5-point
 // Gauss-Legendre quadrature of dh/T.
-#define ATMRT_MAX_ATM_SEGMENTS 64
+// Any number of segments (the reference's AtmosphereDef holds `Vec`s: README.md:283-323, params.rs:453-454): the table is a
+// 32-byte header followed, in the same allocation, by its n segments — one 96-byte record each, so the parameters of the
+// wave-uniform hinted layer are one run of scalar loads and a per-lane layer is one gather base.
+struct AtmSeg {
+  double hb;    // reference altitude of the segment
+  double tb;    // temperature at hb
+  double pb;    // pressure at hb
+  double lapse; // c1 = dT/dh at hb
+  double from;  // segment k >= 1 applies for h >= from
+  double expo;  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
+  double c2;
+  double c3;
+  double rtb;   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
+  // atm_certify: the part [safe_lo, safe_hi) of the segment over which T, p, p/T, Z and n are PROVEN to stay inside the operand range of
+  // the GPU's division / square-root shortcuts (detmath.h); empty (lo = +inf) when nothing can be proven.  An evaluation outside it
+  // takes the IEEE operations, so a pathological atmosphere (a spline that overshoots to 30 K, a pressure of 1e308 Pa) is slower but
+  // still bit-identical to the host.
+  double safe_lo, safe_hi;
+  int32_t cubic; // 1: a knot interval of a Spline temperature function
+  int32_t _pad;
+};
 struct AtmTable {
   int32_t n;
   int32_t _pad;
-  double hb[ATMRT_MAX_ATM_SEGMENTS];    // reference altitude of segment k
-  double tb[ATMRT_MAX_ATM_SEGMENTS];    // temperature at hb
-  double pb[ATMRT_MAX_ATM_SEGMENTS];    // pressure at hb
-  double lapse[ATMRT_MAX_ATM_SEGMENTS]; // c1 = dT/dh at hb
-  double from[ATMRT_MAX_ATM_SEGMENTS];  // segment k >= 1 applies for h >= from[k]
-  double expo[ATMRT_MAX_ATM_SEGMENTS];  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
-  double c2[ATMRT_MAX_ATM_SEGMENTS];
-  double c3[ATMRT_MAX_ATM_SEGMENTS];
-  int32_t cubic[ATMRT_MAX_ATM_SEGMENTS];
-  double k_refr;                        // (n - 1) = k_refr * (p/T) / Z
-  double rtb[ATMRT_MAX_ATM_SEGMENTS];   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
-  // atm_certify: the part [safe_lo, safe_hi) of segment k over which T, p, p/T, Z and n are PROVEN to stay inside the operand range of
-  // the GPU's division / square-root shortcuts (detmath.h); empty (lo = +inf) when nothing can be proven.  An evaluation outside it
-  // takes the IEEE operations, so a pathological atmosphere (a spline that overshoots to 30 K, a pressure of 1e308 Pa) is slower but
-  // still bit-identical to the host.  [alt_lo, alt_hi]: the altitudes at which a path-length step may use the shortcuts.
-  double safe_lo[ATMRT_MAX_ATM_SEGMENTS], safe_hi[ATMRT_MAX_ATM_SEGMENTS];
-  double alt_lo, alt_hi;
+  double k_refr;         // (n - 1) = k_refr * (p/T) / Z
+  double alt_lo, alt_hi; // the altitudes at which a path-length step may use the shortcuts (atm_certify)
+  ATMRT_HD const AtmSeg& seg(int k) const { return reinterpret_cast<const AtmSeg*>(this + 1)[k]; }
+  ATMRT_HD AtmSeg& seg(int k) { return reinterpret_cast<AtmSeg*>(this + 1)[k]; }
 };
+static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 96, "device and host read the table as header + records");
+// the table in the constant address space (it is read-only for a whole launch): wave-uniform indices become scalar loads
+#if defined(__HIPCC__)
+typedef const __attribute__((address_space(4))) AtmTable* AtmConstTable;
+typedef const __attribute__((address_space(4))) AtmSeg* AtmConstSeg;
+__device__ __forceinline__ AtmConstTable atm_const_table(const AtmTable& a) { return (AtmConstTable)(uintptr_t)&a; }
+__device__ __forceinline__ AtmConstSeg atm_const_seg(const AtmTable& a, int k) { return (AtmConstSeg)((uintptr_t)&a + sizeof(AtmTable)) + k; }
+#endif
 
+// Atmosphere::layer: the last segment k >= 1 with h >= from, else 0 (from is non-decreasing over k >= 1; a NaN altitude falls to 0).
+// Short tables are searched from the top like the layer list of a physical atmosphere; long ones (a radiosonde spline) by bisection —
+// the same index either way.
 ATMRT_HD int atm_layer(const AtmTable& a, double h) {
-  for (int k = a.n - 1; k >= 1; k--)
-    if (h >= a.from[k]) return k;
-  return 0;
+  const int n = a.n;
+  if (n <= 12) {
+    for (int k = n - 1; k >= 1; k--)
+      if (h >= a.seg(k).from) return k;
+    return 0;
+  }
+  int lo = 0, hi = n; // invariant: (lo == 0 or h >= from[lo]) and (hi == n or !(h >= from[hi]))
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (h >= a.seg(mid).from) lo = mid;
+    else hi = mid;
+  }
+  return lo;
 }
 
 ATMRT_HD double seg_temperature(double tb, double c1, double c2, double c3, double dh) {
@@ -101,31 +131,46 @@ ATMRT_HD double seg_pressure_ratio(int cubic, double hb, double tb, double c1, d
   return dm_exp(expo * (h - hb));
 }
 ATMRT_HD double atm_pressure_ratio(const AtmTable& a, int k, double h) {
-  return seg_pressure_ratio(a.cubic[k], a.hb[k], a.tb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+  return seg_pressure_ratio(a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
 }
 ATMRT_HD double atm_seg_temperature(const AtmTable& a, int k, double h) {
-  if (a.cubic[k]) return seg_temperature(a.tb[k], a.lapse[k], a.c2[k], a.c3[k], h - a.hb[k]);
-  return a.tb[k] + a.lapse[k] * (h - a.hb[k]);
+  if (a.seg(k).cubic) return seg_temperature(a.seg(k).tb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, h - a.seg(k).hb);
+  return a.seg(k).tb + a.seg(k).lapse * (h - a.seg(k).hb);
 }
 
-// Atmosphere::from_def (params.rs:514).  Returns 0, or a negative code: -1 bad counts, -2 altitudes not increasing,
-// -3 no temperature anchor (all Linear without a fixed point), -4 bad spline, -5 too many segments.
-ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTable& out) {
+// Host storage of a table: the header and its records in one block (what prepare_frame uploads as it is).
+struct AtmTableBuf {
+  std::vector<uint64_t> raw;
+  AtmTable& table() { return *reinterpret_cast<AtmTable*>(raw.data()); }
+  const AtmTable& table() const { return *reinterpret_cast<const AtmTable*>(raw.data()); }
+  size_t bytes() const { return sizeof(AtmTable) + (size_t)table().n * sizeof(AtmSeg); }
+  void alloc(size_t segments) { raw.assign((sizeof(AtmTable) + (segments ? segments : 1) * sizeof(AtmSeg)) / sizeof(uint64_t), 0); }
+};
+
+// Atmosphere::from_def (params.rs:514).  Returns 0, or a negative code: -1 bad counts or kinds, -2 altitudes not increasing,
+// -3 no temperature anchor (all Linear without a fixed point), -4 bad spline.  Any number of functions and of spline points.
+inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTableBuf& buf) {
   const double gmr = 9.80665 * 0.0289644 / 8.31432;
   const int nf = def.n_functions;
-  if (nf < 1 || nf > ATMRT_MAX_ATM_FUNCTIONS) return -1;
-  for (int k = 0; k < ATMRT_MAX_ATM_SEGMENTS; k++) {
-    out.hb[k] = out.tb[k] = out.pb[k] = out.lapse[k] = out.from[k] = out.expo[k] = out.c2[k] = out.c3[k] = out.rtb[k] = 0.0;
-    out.cubic[k] = 0;
+  if (nf < 1 || !def.functions) return -1;
+  size_t cap = 0; // a Linear function is one segment, a Spline at most its knot intervals + the two linear continuations
+  for (int j = 0; j < nf; j++) {
+    const atmrt_temp_function_t& fn = def.functions[j];
+    if (fn.kind == ATMRT_TEMP_LINEAR) cap += 1;
+    else if (fn.kind == ATMRT_TEMP_SPLINE) {
+      if (fn.n_points < 2 || !fn.point_altitude || !fn.point_temperature) return -4;
+      cap += (size_t)fn.n_points + 1;
+    } else return -1;
   }
-  out._pad = 0;
+  if (cap > (size_t)1 << 24) return -1;
+  buf.alloc(cap);
+  AtmTable& out = buf.table();
   for (int j = 2; j < nf; j++)
     if (!(def.functions[j].altitude > def.functions[j - 1].altitude)) return -2;
   // ---- segments, function by function; `owner` remembers which function a segment belongs to
   int n = 0;
-  int owner[ATMRT_MAX_ATM_SEGMENTS];
-  int first_seg[ATMRT_MAX_ATM_FUNCTIONS + 1];
-  bool anchored[ATMRT_MAX_ATM_FUNCTIONS];
+  std::vector<int> owner(cap), first_seg((size_t)nf + 1);
+  std::vector<char> anchored((size_t)nf);
   for (int j = 0; j < nf; j++) {
     const atmrt_temp_function_t& fn = def.functions[j];
     const bool has_lo = j > 0, has_hi = j + 1 < nf;
@@ -133,22 +178,21 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
     first_seg[j] = n;
     anchored[j] = false;
     if (fn.kind == ATMRT_TEMP_LINEAR) {
-      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
       owner[n] = j;
-      out.from[n] = lo;
-      out.lapse[n] = fn.gradient;
+      out.seg(n).from = lo;
+      out.seg(n).lapse = fn.gradient;
       n++;
       continue;
     }
     if (fn.kind != ATMRT_TEMP_SPLINE) return -1;
     const int np = fn.n_points;
-    if (np < 2 || np > ATMRT_MAX_SPLINE_POINTS) return -4;
+    if (np < 2) return -4;
     const double* x = fn.point_altitude;
     const double* y = fn.point_temperature;
     for (int i = 1; i < np; i++)
       if (!(x[i] > x[i - 1])) return -4;
     // second derivatives m[i] of the interpolating cubic spline (Thomas algorithm)
-    double m[ATMRT_MAX_SPLINE_POINTS], cp[ATMRT_MAX_SPLINE_POINTS], dp[ATMRT_MAX_SPLINE_POINTS];
+    std::vector<double> m((size_t)np), cp((size_t)np), dp((size_t)np);
     {
       double b0, c0, d0, an, bn, dn;
       if (fn.boundary == ATMRT_SPLINE_DERIVATIVES) {
@@ -179,46 +223,43 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
     }
     // linear continuation below the first knot
     if (!has_lo || lo < x[0]) {
-      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
       double hh = x[1] - x[0];
       owner[n] = j;
-      out.from[n] = lo;
-      out.hb[n] = x[0];
-      out.tb[n] = y[0];
-      out.lapse[n] = (y[1] - y[0]) / hh - hh * (2.0 * m[0] + m[1]) / 6.0; // S'(x0)
+      out.seg(n).from = lo;
+      out.seg(n).hb = x[0];
+      out.seg(n).tb = y[0];
+      out.seg(n).lapse = (y[1] - y[0]) / hh - hh * (2.0 * m[0] + m[1]) / 6.0; // S'(x0)
       n++;
     }
     for (int i = 0; i + 1 < np; i++) {
       if (has_hi && x[i] >= hi) break;          // interval entirely above this function's range
       if (has_lo && x[i + 1] <= lo) continue;   // interval entirely below it
-      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
       double hh = x[i + 1] - x[i];
       owner[n] = j;
-      out.from[n] = (has_lo && lo > x[i]) ? lo : x[i];
-      out.hb[n] = x[i];
-      out.tb[n] = y[i];
-      out.lapse[n] = (y[i + 1] - y[i]) / hh - hh * (2.0 * m[i] + m[i + 1]) / 6.0;
-      out.c2[n] = m[i] / 2.0;
-      out.c3[n] = (m[i + 1] - m[i]) / (6.0 * hh);
-      out.cubic[n] = 1;
+      out.seg(n).from = (has_lo && lo > x[i]) ? lo : x[i];
+      out.seg(n).hb = x[i];
+      out.seg(n).tb = y[i];
+      out.seg(n).lapse = (y[i + 1] - y[i]) / hh - hh * (2.0 * m[i] + m[i + 1]) / 6.0;
+      out.seg(n).c2 = m[i] / 2.0;
+      out.seg(n).c3 = (m[i + 1] - m[i]) / (6.0 * hh);
+      out.seg(n).cubic = 1;
       n++;
     }
     // linear continuation above the last knot
     if (!has_hi || hi > x[np - 1]) {
-      if (n >= ATMRT_MAX_ATM_SEGMENTS) return -5;
       double hh = x[np - 1] - x[np - 2];
       owner[n] = j;
-      out.from[n] = x[np - 1];
-      out.hb[n] = x[np - 1];
-      out.tb[n] = y[np - 1];
-      out.lapse[n] = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0; // S'(x_last)
+      out.seg(n).from = x[np - 1];
+      out.seg(n).hb = x[np - 1];
+      out.seg(n).tb = y[np - 1];
+      out.seg(n).lapse = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0; // S'(x_last)
       n++;
     }
     anchored[j] = true;
   }
   first_seg[nf] = n;
   out.n = n;
-  out.from[0] = 0.0; // segment 0 extends to -inf
+  out.seg(0).from = 0.0; // segment 0 extends to -inf
   // ---- absolute temperature of the Linear functions: the fixed point, else continuity with an anchored neighbour
   if (def.has_temperature_fixed_point) {
     int jt = 0;
@@ -226,8 +267,8 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
       if (def.temperature_altitude >= def.functions[j].altitude) { jt = j; break; }
     if (def.functions[jt].kind == ATMRT_TEMP_LINEAR && !anchored[jt]) {
       int k = first_seg[jt];
-      out.hb[k] = jt == 0 ? def.temperature_altitude : out.from[k];
-      out.tb[k] = def.temperature - out.lapse[k] * (def.temperature_altitude - out.hb[k]);
+      out.seg(k).hb = jt == 0 ? def.temperature_altitude : out.seg(k).from;
+      out.seg(k).tb = def.temperature - out.seg(k).lapse * (def.temperature_altitude - out.seg(k).hb);
       anchored[jt] = true;
     }
   }
@@ -240,32 +281,32 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
       int k = first_seg[j];
       if (j > 0 && anchored[j - 1]) { // continuous with the function below at this function's start altitude
         int kl = first_seg[j] - 1;
-        out.hb[k] = out.from[k];
-        out.tb[k] = atm_seg_temperature(out, kl, out.from[k]);
+        out.seg(k).hb = out.seg(k).from;
+        out.seg(k).tb = atm_seg_temperature(out, kl, out.seg(k).from);
         anchored[j] = true;
       } else if (j + 1 < nf && anchored[j + 1]) { // continuous with the function above at its start altitude
         int ku = first_seg[j + 1];
         double top = def.functions[j + 1].altitude;
-        out.hb[k] = j == 0 ? top : out.from[k];
-        out.tb[k] = atm_seg_temperature(out, ku, top) - out.lapse[k] * (top - out.hb[k]);
+        out.seg(k).hb = j == 0 ? top : out.seg(k).from;
+        out.seg(k).tb = atm_seg_temperature(out, ku, top) - out.seg(k).lapse * (top - out.seg(k).hb);
         anchored[j] = true;
       }
     }
   }
   for (int k = 0; k < n; k++) {
-    out.expo[k] = out.cubic[k] ? -gmr : (out.lapse[k] != 0.0 ? -gmr / out.lapse[k] : -gmr / out.tb[k]);
-    out.rtb[k] = 1.0 / out.tb[k];
+    out.seg(k).expo = out.seg(k).cubic ? -gmr : (out.seg(k).lapse != 0.0 ? -gmr / out.seg(k).lapse : -gmr / out.seg(k).tb);
+    out.seg(k).rtb = 1.0 / out.seg(k).tb;
   }
   // ---- pressure: chain outwards from the pressure fixed point
   int jp = atm_layer(out, def.pressure_altitude);
-  out.pb[jp] = def.pressure / atm_pressure_ratio(out, jp, def.pressure_altitude);
+  out.seg(jp).pb = def.pressure / atm_pressure_ratio(out, jp, def.pressure_altitude);
   for (int k = jp + 1; k < n; k++) {
-    double pk = out.pb[k - 1] * atm_pressure_ratio(out, k - 1, out.from[k]); // p at the boundary, from below
-    out.pb[k] = pk / atm_pressure_ratio(out, k, out.from[k]);
+    double pk = out.seg(k - 1).pb * atm_pressure_ratio(out, k - 1, out.seg(k).from); // p at the boundary, from below
+    out.seg(k).pb = pk / atm_pressure_ratio(out, k, out.seg(k).from);
   }
   for (int k = jp - 1; k >= 0; k--) {
-    double pk = out.pb[k + 1] * atm_pressure_ratio(out, k + 1, out.from[k + 1]); // p at the boundary, from above
-    out.pb[k] = pk / atm_pressure_ratio(out, k, out.from[k + 1]);
+    double pk = out.seg(k + 1).pb * atm_pressure_ratio(out, k + 1, out.seg(k + 1).from); // p at the boundary, from above
+    out.seg(k).pb = pk / atm_pressure_ratio(out, k, out.seg(k + 1).from);
   }
   {
     const double k0 = 238.0185, k1 = 5792105.0, k2 = 57.362, k3 = 167917.0;
@@ -292,13 +333,13 @@ ATMRT_HD int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTa
 // The predicate is monotone: a sub-interval of an interval that passes passes.
 inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double hi) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
-  const double tb = t.tb[k], pb = t.pb[k];
+  const double tb = t.seg(k).tb, pb = t.seg(k).pb;
   if (!(tb >= 1.0 && tb <= 1.0e5) || !(pb >= 1.0e-250 && pb <= 1.0e250)) return false;
   double tmin, tmax, pmin, pmax;
-  if (t.cubic[k]) {
-    const double c1 = t.lapse[k], c2 = t.c2[k], c3 = t.c3[k];
-    const double d1 = hi - t.hb[k]; // T over [hb, hi]: the evaluation points and the quadrature nodes
-    if (!(d1 >= 0.0) || !(lo >= t.hb[k])) return false;
+  if (t.seg(k).cubic) {
+    const double c1 = t.seg(k).lapse, c2 = t.seg(k).c2, c3 = t.seg(k).c3;
+    const double d1 = hi - t.seg(k).hb; // T over [hb, hi]: the evaluation points and the quadrature nodes
+    if (!(d1 >= 0.0) || !(lo >= t.seg(k).hb)) return false;
     tmin = tmax = tb;
     double cand[3] = {d1, -1.0, -1.0};
     if (c3 != 0.0) {
@@ -322,9 +363,9 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
     tmax += 1.0e-6 * (dm_fabs(tmin) + dm_fabs(tmax)) + 1.0e-6;
     if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
     pmax = pb;
-    pmin = pb * dm_exp(t.expo[k] * d1 / tmin); // expo < 0
+    pmin = pb * dm_exp(t.seg(k).expo * d1 / tmin); // expo < 0
   } else {
-    if (t.lapse[k] != 0.0 && !(dm_fabs(t.expo[k]) <= 1.0e6)) return false; // a lapse rate below 4e-8 K/m: the exponent of pow runs away
+    if (t.seg(k).lapse != 0.0 && !(dm_fabs(t.seg(k).expo) <= 1.0e6)) return false; // a lapse rate below 4e-8 K/m: the exponent of pow runs away
     const double t0 = atm_seg_temperature(t, k, lo), t1 = atm_seg_temperature(t, k, hi);
     tmin = t0 < t1 ? t0 : t1;
     tmax = t0 < t1 ? t1 : t0;
@@ -346,9 +387,9 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
 // [max(-100 km, 1 km - radius), 10 000 km].  Nothing is certified for a step outside 1 mm .. 1e8 m, a radius outside 1 km .. 1e12 m
 // or a refractivity constant outside 1e-12 .. 1e-3 (a wavelength on a resonance of the dispersion formula).
 inline void atm_certify(AtmTable& t, bool spherical, double radius, double step) {
-  for (int k = 0; k < ATMRT_MAX_ATM_SEGMENTS; k++) {
-    t.safe_lo[k] = dm_inf();
-    t.safe_hi[k] = -dm_inf();
+  for (int k = 0; k < t.n; k++) {
+    t.seg(k).safe_lo = dm_inf();
+    t.seg(k).safe_hi = -dm_inf();
   }
   t.alt_lo = dm_inf();
   t.alt_hi = -dm_inf();
@@ -361,12 +402,12 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
   t.alt_lo = gl;
   t.alt_hi = gh;
   for (int k = 0; k < t.n; k++) {
-    const double L = k > 0 && t.from[k] > gl ? t.from[k] : gl;
-    const double H = k + 1 < t.n && t.from[k + 1] < gh ? t.from[k + 1] : gh;
+    const double L = k > 0 && t.seg(k).from > gl ? t.seg(k).from : gl;
+    const double H = k + 1 < t.n && t.seg(k + 1).from < gh ? t.seg(k + 1).from : gh;
     if (!(L < H)) continue;
     double lo = L, hi = H;
     if (!atm_interval_certified(t, k, lo, hi)) {
-      const double cands[5] = {0.0, t.hb[k], 0.5 * (L + H), L, H};
+      const double cands[5] = {0.0, t.seg(k).hb, 0.5 * (L + H), L, H};
       double a = 0.0;
       bool have = false;
       for (int i = 0; i < 5 && !have; i++) {
@@ -399,15 +440,15 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
       }
       if (!atm_interval_certified(t, k, lo, hi) || !(lo < hi)) continue;
     }
-    t.safe_lo[k] = lo;
-    t.safe_hi[k] = hi;
+    t.seg(k).safe_lo = lo;
+    t.seg(k).safe_hi = hi;
   }
 }
 
 ATMRT_HD double atm_temperature(const AtmTable& a, double h) { return atm_seg_temperature(a, atm_layer(a, h), h); }
 ATMRT_HD double atm_pressure(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
-  return a.pb[k] * atm_pressure_ratio(a, k, h);
+  return a.seg(k).pb * atm_pressure_ratio(a, k, h);
 }
 
 // FAST selects the GPU's shortcut sequences (dm_div ...: the IEEE result for in-range operands only) and is passed as true only for
@@ -528,7 +569,7 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, doub
 // generic evaluation, valid for any atmosphere at any altitude.
 ATMRT_HD double refr_n(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
-  return refr_n_layer(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+  return refr_n_layer(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
 }
 ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   const double eps = 0.01;
@@ -548,17 +589,16 @@ ATMRT_HD double refr_dn(const AtmTable& a, double h) {
 template <bool CUBIC>
 __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, double h, int& hint, bool& certified) {
   const int ku = __builtin_amdgcn_readfirstlane(hint);
-  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
-  const ConstTable ka = (ConstTable)(uintptr_t)&a;
-  if (__all(h >= ka->safe_lo[ku] && h < ka->safe_hi[ku])) {
+  const AtmConstTable ka = atm_const_table(a);
+  const AtmConstSeg ks = atm_const_seg(a, ku);
+  if (__all(h >= ks->safe_lo && h < ks->safe_hi)) {
     certified = true;
-    return refr_n_layer<CUBIC, true>(ka->k_refr, ka->cubic[ku], ka->hb[ku], ka->tb[ku], ka->pb[ku], ka->lapse[ku], ka->c2[ku], ka->c3[ku],
-                                     ka->expo[ku], h);
+    return refr_n_layer<CUBIC, true>(ka->k_refr, ks->cubic, ks->hb, ks->tb, ks->pb, ks->lapse, ks->c2, ks->c3, ks->expo, h);
   }
   const int k = atm_layer(a, h);
   hint = k;
-  certified = h >= a.safe_lo[k] && h < a.safe_hi[k];
-  return refr_n_layer<CUBIC, true>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+  certified = h >= a.seg(k).safe_lo && h < a.seg(k).safe_hi;
+  return refr_n_layer<CUBIC, true>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
 }
 #endif
 
@@ -573,12 +613,11 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   const double h1 = h - eps, h2 = h + eps;
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
-  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
-  const ConstTable ka = (ConstTable)(uintptr_t)&a;
-  if (__all(h1 >= ka->safe_lo[ku] && h2 < ka->safe_hi[ku])) {
-    const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], rtb = ka->rtb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
-                 c3 = ka->c3[ku], expo = ka->expo[ku];
-    const int cubic = ka->cubic[ku];
+  const AtmConstTable ka = atm_const_table(a);
+  const AtmConstSeg ks = atm_const_seg(a, ku);
+  if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
+    const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const int cubic = ks->cubic;
     double n1, n2;
     refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
     dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
@@ -589,10 +628,10 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   {
     const int k = atm_layer(a, h);
     hint = k;
-    n = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+    n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
     const int k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
-    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k1], a.hb[k1], a.tb[k1], a.pb[k1], a.lapse[k1], a.c2[k1], a.c3[k1], a.expo[k1], h1);
-    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k2], a.hb[k2], a.tb[k2], a.pb[k2], a.lapse[k2], a.c2[k2], a.c3[k2], a.expo[k2], h2);
+    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
+    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
     dn = (n2 - n1) / (2.0 * eps);
     return false;
   }
@@ -959,9 +998,9 @@ ATMRT_HD double ray_accel_generic(const AtmTable& a, bool spherical, double radi
   const double h = spherical ? pa - radius : pa, h1 = h - eps, h2 = h + eps;
   const int k = atm_layer(a, h), k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
   hint = k; // the hint follows the lane, so that the fast path resumes once the wavefront is back inside one certified interval
-  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
-  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k1], a.hb[k1], a.tb[k1], a.pb[k1], a.lapse[k1], a.c2[k1], a.c3[k1], a.expo[k1], h1);
-  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.cubic[k2], a.hb[k2], a.tb[k2], a.pb[k2], a.lapse[k2], a.c2[k2], a.c3[k2], a.expo[k2], h2);
+  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
+  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
   const double dn = (n2 - n1) / (2.0 * eps);
   return accel_rhs<false>(spherical, pa, pb, n, dn);
 }
@@ -979,12 +1018,11 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   const double h = spherical ? a - radius : a, h1 = h - eps, h2 = h + eps;
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
-  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
-  const ConstTable ka = (ConstTable)(uintptr_t)&atm;
-  if (__all(h1 >= ka->safe_lo[ku] && h2 < ka->safe_hi[ku] && !(dm_fabs(b) > ACCEL_FAST_MAX_B))) {
-    const double k_refr = ka->k_refr, hb = ka->hb[ku], tb = ka->tb[ku], rtb = ka->rtb[ku], pb = ka->pb[ku], lapse = ka->lapse[ku], c2 = ka->c2[ku],
-                 c3 = ka->c3[ku], expo = ka->expo[ku];
-    const int cubic = ka->cubic[ku];
+  const AtmConstTable ka = atm_const_table(atm);
+  const AtmConstSeg ks = atm_const_seg(atm, ku);
+  if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi && !(dm_fabs(b) > ACCEL_FAST_MAX_B))) {
+    const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const int cubic = ks->cubic;
     double n, n1, n2;
     refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
     const double dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
@@ -1064,7 +1102,7 @@ ATMRT_HD RayState stepper_next(Stepper& s, const AtmTable& atm, bool spherical, 
 }
 ATMRT_HD bool atm_has_cubic(const AtmTable& a) {
   for (int k = 0; k < a.n; k++)
-    if (a.cubic[k]) return true;
+    if (a.seg(k).cubic) return true;
   return false;
 }
 
@@ -1076,8 +1114,7 @@ ATMRT_HD bool atm_has_cubic(const AtmTable& a) {
 // Anything else (a ray that left for 1e300 m, NaN): the IEEE square root.
 ATMRT_HD bool calc_dist_in_band(const AtmTable& atm, double h) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef const __attribute__((address_space(4))) AtmTable* ConstTable;
-  const ConstTable ka = (ConstTable)(uintptr_t)&atm;
+  const AtmConstTable ka = atm_const_table(atm);
   return h >= ka->alt_lo && h <= ka->alt_hi;
 #else
   return h >= atm.alt_lo && h <= atm.alt_hi;

@@ -23,18 +23,65 @@ from .config import Config
 
 
 class Context:
-    """Owns one atmrt_ctx (one HIP device)."""
+    """Owns one atmrt_ctx: one HIP device, or — Context.multi([...]) — several devices of this process behind one handle
+    (the library cuts every frame into pixel-column tiles, one per device; include/atmrt.h "several GPUs of one node")."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, devices=None):
         self.lib = _lib.load()
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
         h = C.c_void_p()
-        rc = self.lib.atmrt_ctx_create(C.byref(h), device)
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = self.lib.atmrt_ctx_create_multi(C.byref(h), arr, len(devices))
+            device = devices[0] if devices else 0
+        else:
+            if device is None:
+                device = int(os.environ.get("LOCAL_RANK", "0"))
+            rc = self.lib.atmrt_ctx_create(C.byref(h), device)
         if rc != 0:
             raise AtmrtError(rc, self.lib.atmrt_last_error(None).decode())
         self.handle = h
         self.device = device
+        self.devices = devices or [device]
+        self._transport = None
+
+    @classmethod
+    def multi(cls, devices):
+        return cls(devices=devices)
+
+    # ---- one process per GPU: this context becomes rank `rank` of `world` ranks that share every frame -------------------
+    def comm_unique_id(self):
+        """ncclGetUniqueId through the library: 128 bytes for the other ranks' comm_init_rank."""
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+        rc = self.lib.atmrt_comm_unique_id(buf)
+        if rc != 0:
+            raise AtmrtError(rc, self.lib.atmrt_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id, rank, world):
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self.check(self.lib.atmrt_ctx_comm_init_rank(self.handle, buf, rank, world))
+
+    def comm_init_external(self, rank, world, all_gather):
+        """all_gather(send: memoryview, recv: memoryview) moves host bytes between the ranks (MPI, gloo, a test double)."""
+        def thunk(_user, send, recv, nbytes):
+            try:
+                all_gather((C.c_uint8 * nbytes).from_address(send), (C.c_uint8 * (nbytes * world)).from_address(recv))
+                return 0
+            except Exception as exc:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                self._transport_error = exc
+                return 1
+        self._transport = _abi.ALL_GATHER_FN(thunk)  # keep the trampoline alive as long as the context
+        self.check(self.lib.atmrt_ctx_comm_init_external(self.handle, rank, world, self._transport, None))
+
+    def comm_timings(self):
+        t = _abi.CommTimings()
+        self.check(self.lib.atmrt_last_comm_timings(self.handle, C.byref(t)))
+        out = {k: getattr(t, k) for k, _ in _abi.CommTimings._fields_ if k != "_pad"}
+        out["route"] = _abi.ROUTES.get(out["route"], out["route"])
+        return out
 
     def check(self, rc):
         if rc != 0:
@@ -154,6 +201,29 @@ class Generator:
         return steps.value, ms.value
 
 
+    def generate_image_device(self, images):
+        """The WHOLE [H][W] frame left in HBM on every device of the context (atmrt_generate_image_device): `images` is one
+        _abi.DevicePlanes per device (a single one for a plain or rank context).  Returns (ray_steps, device_ms)."""
+        self._configure()
+        if isinstance(images, _abi.DevicePlanes):
+            images = [images]
+        arr = (_abi.DevicePlanes * len(images))(*images)
+        steps, ms = C.c_uint64(), C.c_double()
+        self.ctx.check(self.ctx.lib.atmrt_generate_image_device(self.ctx.handle, arr, C.byref(steps), C.byref(ms)))
+        return steps.value, ms.value
+
+    def image_hits_device(self, height, width, device=None):
+        """The trace-point lists of the frame generate_image_device just produced, in the image's pixel order, as torch tensors on
+        `device` (default: the context's): atmrt_image_hits_device.  Collective over the ranks of a rank context."""
+        import torch
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.atmrt_image_hits_device(self.ctx.handle, None, C.byref(n)))
+        devs = self.ctx.devices if device is None else [device]
+        ts = [_hit_tensors(n.value, height, width, torch.device("cuda", d)) for d in devs]
+        pods = (_abi.DeviceHits * len(ts))(*[_abi.DeviceHits(capacity=n.value, **{k: v.data_ptr() for k, v in t.items()}) for t in ts])
+        self.ctx.check(self.ctx.lib.atmrt_image_hits_device(self.ctx.handle, pods, None))
+        return ts[0] if len(ts) == 1 else ts
+
     def last_hits_device(self, height, width):
         """Complete trace-point lists of the frame generate_device just produced, as torch tensors on the context's device:
         {hit_offset [H][W], lat, lon, distance, elevation, path_length, normal [n][3], color_tag, rgba [n][4]}."""
@@ -161,13 +231,7 @@ class Generator:
         n = C.c_uint64()
         self.ctx.check(self.ctx.lib.atmrt_last_hits_device(self.ctx.handle, None, C.byref(n)))
         n = n.value
-        dev = torch.device("cuda", self.ctx.device)
-        f64 = dict(dtype=torch.float64, device=dev)
-        t = {k: torch.empty(n, **f64) for k in ("lat", "lon", "distance", "elevation", "path_length")}
-        t["normal"] = torch.empty((n, 3), **f64)
-        t["rgba"] = torch.empty((n, 4), **f64)
-        t["color_tag"] = torch.empty(n, dtype=torch.int32, device=dev)
-        t["hit_offset"] = torch.empty((height, width), dtype=torch.int64, device=dev)
+        t = _hit_tensors(n, height, width, torch.device("cuda", self.ctx.device))
         pod = _abi.DeviceHits(capacity=n, **{k: v.data_ptr() for k, v in t.items()})
         self.ctx.check(self.ctx.lib.atmrt_last_hits_device(self.ctx.handle, C.byref(pod), None))
         return t
@@ -182,6 +246,28 @@ class Generator:
         t = _abi.Timings()
         self.ctx.check(self.ctx.lib.atmrt_last_timings(self.ctx.handle, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _abi.Timings._fields_}
+
+
+def _hit_tensors(n, height, width, dev):
+    """Device arrays laid out like the hit arrays of atmrt_result_t (atmrt_device_hits_t)."""
+    import torch
+    f64 = dict(dtype=torch.float64, device=dev)
+    t = {k: torch.empty(n, **f64) for k in ("lat", "lon", "distance", "elevation", "path_length")}
+    t["normal"] = torch.empty((n, 3), **f64)
+    t["rgba"] = torch.empty((n, 4), **f64)
+    t["color_tag"] = torch.empty(n, dtype=torch.int32, device=dev)
+    t["hit_offset"] = torch.empty((height, width), dtype=torch.int64, device=dev)
+    return t
+
+
+def image_planes(height, width, dev):
+    """[H][W] planes of a whole frame in HBM + the atmrt_device_planes_t that points at them."""
+    import torch
+    f64 = dict(dtype=torch.float64, device=dev)
+    t = {k: torch.empty((height, width), **f64) for k in ("azimuth", "elevation_angle", "lat", "lon", "distance", "elevation", "path_length")}
+    t["normal"] = torch.empty((3, height, width), **f64)
+    t["hit_count"] = torch.empty((height, width), dtype=torch.int32, device=dev)
+    return t, _abi.DevicePlanes(**{k: v.data_ptr() for k, v in t.items()})
 
 
 class FastGenerator(Generator):

@@ -5,10 +5,11 @@
 
 A "step" is one full frame of the headline workload (4096x2048 panorama, 3x3 synthetic DTED level-2
 tiles, simulation_step 100 m, max_distance 200 km, spherical Earth + US-76 refraction) through the C ABI
-(atmrt_generate_device): terrain tiles and parameters are resident in HBM before the timed region, the
-per-pixel result planes stay in HBM.  With N > 1 (one process per GPU under torch.distributed.run) every rank
-marches its own pixel-column tile; the tiles' planes (one slab per rank) are all-gathered over RCCL/xGMI by ONE collective and
-permuted into the [H][W] image inside the step.
+(atmrt_generate_image_device): terrain tiles and parameters are resident in HBM before the timed region, the
+per-pixel result planes stay in HBM.  With N > 1 (one process per GPU; `python bench.py --gpus N` starts the N ranks itself as a
+torch.distributed.run child, or run it under torchrun) every rank marches the pixel-column tile the LIBRARY assigns it, and the
+library itself — C++ below the C ABI, csrc/atmrt_multi.hip — all-gathers the tiles' planes (one 84 B/pixel slab per rank) with ONE
+ncclAllGather over RCCL/xGMI and permutes them into the [H][W] image, inside the step.
 
 Prints ONE JSON line (rank 0).  `value` = ray-steps marched by all ranks per second, where a ray-step is one
 sample-pair evaluation of get_single_pixel's loop under the reference's termination rule (utils.rs:211-287).
@@ -92,6 +93,21 @@ def main():
     ap.add_argument("--step", type=float, default=None, help="simulation_step override [m]")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: one process per GPU is the contract, so start the N ranks as a child
+        # torch.distributed.run job (this process has not touched the GPU and never will), pass its JSON line through and exit with
+        # its code.  Under an outer torchrun (RANK set) this branch is not taken.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd)}")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     import numpy as np
     import torch
     from atm_raytracer_amd import _abi, generators, synth
@@ -101,9 +117,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    if args.width % max(world, 1) != 0:
-        # pixel-column tiles must be equal: all_gather_into_tensor with unequal counts hangs or corrupts (checked before any collective)
-        raise SystemExit(f"bench.py: --width {args.width} is not a multiple of the {world} ranks")
     dist = None
     # under torch.distributed.run the process group (RCCL) is always created, so a 1-rank launch exercises the same
     # all-gather code path as N ranks; a plain `python bench.py` run has no process group
@@ -126,52 +139,62 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H = args.width, args.height
-    from atm_raytracer_amd.sharding import column_shard
-    c0, c1 = column_shard(W, rank, world)  # pixel-column tiles: rank g owns [g*W/G, (g+1)*W/G)
+    if W < world:
+        raise SystemExit(f"bench.py: --width {W} leaves some of the {world} ranks without a pixel column")
+    # pixel-column tiles, assigned INSIDE the library (csrc/atmrt_multi.hip): rank g owns [g W / G, (g + 1) W / G)
+    c0, c1 = rank * W // world, (rank + 1) * W // world
     wl = c1 - c0
 
     t_setup = time.perf_counter()
     cfg, tiles = synth.scene(args.scene, W, H, generator=args.generator, level=args.dted_level, step=args.step)
-    cfg.params.col_begin, cfg.params.col_end = (c0, c1) if world > 1 else (0, 0)
     cfg.params.terrain_alpha = args.terrain_alpha
     if args.objects:
         synth.add_objects(cfg, n_cyl=args.objects * 7 // 10, n_bill=args.objects - args.objects * 7 // 10)
     ctx = generators.Context(local_rank)
+    if distributed:
+        # The frame's exchange is the library's own (C++, below the C ABI): one ncclAllGather of the tile's 84 B/pixel slab + the
+        # permutation kernel into the [H][W] planes, inside atmrt_generate_image_device.  torch.distributed only carries the
+        # 128-byte RCCL id to the ranks (and the timing reductions below).
+        if backend == "gloo":
+            # rehearsal on one GPU: RCCL refuses two ranks on one device, so the library's transport hook moves the host-staged
+            # tiles over gloo; shard assignment, slab layout, assembly kernels and list gathering are the C++ code of the real run
+            def all_gather(send, recv):
+                dist.all_gather_into_tensor(torch.frombuffer(recv, dtype=torch.uint8), torch.frombuffer(send, dtype=torch.uint8))
+            ctx.comm_init_external(rank, world, all_gather)
+        else:
+            ident = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(ident, 0)
+            ctx.comm_init_rank(bytes(ident.cpu().numpy()), rank, world)
     terrain = generators.Terrain.from_tiles(tiles, ctx)
     log(f"[rank {rank}] scene ready in {time.perf_counter() - t_setup:.1f} s: {W}x{H}, columns [{c0},{c1}), "
         f"{len(tiles)} tiles of {next(iter(tiles.values())).shape}")
 
-    # the shard's result planes are views of ONE slab; with N > 1 the slabs are all-gathered by a single collective per frame and
-    # permuted into the [H][W] image inside the step (atm_raytracer_amd/sharding.py)
-    from atm_raytracer_amd.sharding import ImageGather, PlaneSlab, gather_hits
-    slab = PlaneSlab(H, wl, dev)
-    local = slab.planes
-    pod = slab.device_planes()
-    via_host = distributed and backend == "gloo"
-    gather = ImageGather(slab, world, via_host=via_host) if distributed else None
+    # every rank ends the step with the WHOLE frame in its HBM: [H][W] planes (+ the lists of a multi-hit frame)
+    image, pod = generators.image_planes(H, W, dev)
+    local = {k: (v[..., c0:c1]) for k, v in image.items()}  # this rank's own columns of the frame
 
-    gather_events, gather_ms = [], {}
+    gather_ms, comm_info = {}, {}
     multi_hit = args.terrain_alpha < 1.0 or args.objects > 0
-    gathered_hits = [None, None]
-    image = {}
+    gathered_hits = [None]
 
     def make_step(generator_name):
         cfg.params.generator = _abi.GENERATORS[generator_name]
         gen = generators.make_generator(generators.Params(cfg), terrain)
+        lists = multi_hit or generator_name == "InterpolatingRectilinear"
 
         def step():
-            steps, _ms = gen.generate_device(pod)  # returns after the library's stream has drained
-            if distributed:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                gather_events.append((ev0, ev1))
-                ev0.record()
-                image.update(gather(dist))  # ONE RCCL all-gather of the 88 B/pixel slab + the permutation to [H][W]
-                if multi_hit:  # pixels with several trace points: the variable-length lists as well
-                    hits = gen.last_hits_device(H, wl)
-                    hits.pop("hit_offset")
-                    gathered_hits[:] = gather_hits(image["hit_count"], hits, world, dist, via_host=via_host)
-                ev1.record()
+            # returns after the library's stream has drained: tile -> slab -> ONE all-gather -> [H][W] planes
+            steps, _ms = gen.generate_image_device(pod)
             tm = gen.last_timings()
+            if distributed:
+                ct = ctx.comm_timings()
+                tm["gather_ms"] = ct["gather_ms"] + ct["assemble_ms"]
+                comm_info.update(ct)
+                if lists and multi_hit:  # pixels with several trace points: the variable-length lists as well (2 more collectives)
+                    gathered_hits[0] = gen.image_hits_device(H, W)
+                    comm_info.update(ctx.comm_timings())
             tm["terrain_lookups"] = gen.last_stats()["terrain_lookups"]
             return steps, tm
         return step
@@ -183,7 +206,6 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
-        gather_events.clear()
         t0 = time.perf_counter()
         marched, phase = 0, []
         for _ in range(k_steps):
@@ -202,7 +224,7 @@ def main():
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             elapsed, marched = float(tmax.item()), float(tot.item())
             # the exchange step on its own: mean all-gather time per frame, slowest rank
-            g = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in gather_events]))], dtype=torch.float64, device=dev)
+            g = torch.tensor([float(np.mean([p["gather_ms"] for p in phase]))], dtype=torch.float64, device=dev)
             dist.all_reduce(g, op=dist.ReduceOp.MAX)
             gather_ms[generator_name] = float(g.item())
         return elapsed, marched, phase
@@ -239,7 +261,7 @@ def main():
         mean = lambda k: float(np.mean([p[k] for p in phase]))
         steps_per_launch = mean("ray_steps")
         lookups = mean("terrain_lookups")
-        hits = float((local["hit_count"] > 0).sum().item())  # recorded crossings of the last frame (opaque terrain: one per hit pixel)
+        hits = float((local["hit_count"] > 0).sum().item())  # recorded crossings of this rank's columns in the last frame (opaque terrain: one per hit pixel)
         n_t = float(int(np.ceil(cfg.params.frame.max_distance / cfg.params.simulation_step)))  # samples per ray (utils.rs:191-196)
         n_path = n_t + 3.0                                                                      # path elements per row (utils.rs:160-170)
         per_kernel = {
@@ -298,9 +320,12 @@ def main():
         "roofline": roofline(args.generator, phase),
     }
     if distributed:
-        # inside ms_per_step: one all-gather of the 88 B/pixel slab + the permutation into the [H][W] image (+ the lists of a multi-hit frame)
+        # inside ms_per_step: one all-gather of the 84 B/pixel slab + the permutation into the [H][W] image (+ the lists of a multi-hit frame),
+        # all of it in C++ below the C ABI (csrc/atmrt_multi.hip); the figures are the library's own HIP events, slowest rank
         result["all_gather_ms_per_step"] = gather_ms.get(args.generator)
         result["all_gather_collectives_per_step"] = 1 + (2 if multi_hit else 0)
+        result["world_size_seen"] = dist.get_world_size()
+        result["comm"] = {k: comm_info.get(k) for k in ("route", "world", "bytes_per_rank", "gather_ms", "assemble_ms", "tile_ms_max")}
     if not args.only and args.generator == "Rectilinear":
         # the reference's other two generators on the same workload (secondary lines; `value` above is the per-pixel march)
         e2, m2, ph2 = timed("Fast", args.steps, 1)
@@ -318,16 +343,32 @@ def main():
             result["cpu_baseline"] = {"value": None, "error": repr(exc)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if distributed and rank == 0 and os.environ.get("ATMRT_BENCH_CHECK_GATHER"):
-        full = image["distance"]
-        ok = full.shape == (H, W) and torch.equal(full[:, c0:c1].nan_to_num(-1.0), local["distance"].nan_to_num(-1.0))
-        hits = image["hit_count"]
-        log(f"gathered image check: shape {tuple(full.shape)}, rank-0 shard matches: {bool(ok)}, hit pixels per rank shard: "
-            f"{[int((hits[:, g * wl:(g + 1) * wl] > 0).sum()) for g in range(world)]}")
-        if multi_hit:
-            offsets, lists = gathered_hits
-            log(f"gathered trace-point lists: {lists['lat'].shape[0]} points, sum of hit_count {int(hits.sum())}, "
-                f"last offset + count {int(offsets[-1, -1]) + int(hits[-1, -1])}")
+    if distributed and os.environ.get("ATMRT_BENCH_CHECK_GATHER"):
+        # every rank marches one more frame of the headline generator (collective), then rank 0 computes the same frame on a plain
+        # single-device context and compares what the exchange left in its HBM: every plane, every trace point, every offset
+        make_step(args.generator)()
+        if rank == 0:
+            solo = generators.Context(local_rank)
+            cfg.params.generator = _abi.GENERATORS[args.generator]
+            want = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, solo)).generate()
+            solo.close()
+            hc = torch.from_numpy(want["hit_count"].astype(np.int32)).to(dev)
+            same = bool(torch.equal(image["hit_count"], hc))
+            for k in ("azimuth", "elevation_angle"):
+                same = same and bool(torch.equal(image[k], torch.from_numpy(want[k]).to(dev)))
+            first = torch.from_numpy(want["hit_offset"].astype(np.int64)).to(dev)[hc > 0]
+            for k in ("lat", "lon", "distance", "elevation", "path_length"):
+                same = same and bool(torch.equal(image[k][hc > 0].view(torch.int64), torch.from_numpy(want[k]).to(dev)[first].view(torch.int64)))
+            n_lists = None
+            if gathered_hits[0] is not None:
+                got = gathered_hits[0]
+                n_lists = int(got["lat"].shape[0])
+                same = same and n_lists == want["n_hits"] and bool(torch.equal(got["hit_offset"], torch.from_numpy(want["hit_offset"].astype(np.int64)).to(dev)))
+                for k in ("lat", "lon", "distance", "elevation", "path_length", "normal", "rgba"):
+                    same = same and bool(torch.equal(got[k].view(torch.int64), torch.from_numpy(want[k]).to(dev).view(torch.int64)))
+                same = same and bool(torch.equal(got["color_tag"], torch.from_numpy(want["color_tag"].astype(np.int32)).to(dev)))
+            log(f"gathered image check: {W}x{H} over {world} ranks via {comm_info.get('route')}, {int((hc > 0).sum())} hit pixels, "
+                f"{n_lists if n_lists is not None else 'no'} listed trace points; matches the single-context frame: {same}")
     ctx.close()
     if distributed:
         dist.destroy_process_group()

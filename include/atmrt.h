@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ATMRT_ABI_VERSION 3
+#define ATMRT_ABI_VERSION 4
 
 typedef enum atmrt_status {
   ATMRT_OK = 0,
@@ -97,15 +97,15 @@ typedef struct atmrt_params {
   int32_t generator;           /* atmrt_generator_kind, output.generator */
   uint16_t width;              /* output.width  (u16 as in params.rs:398-402) */
   uint16_t height;             /* output.height */
-  uint16_t col_begin;          /* pixel-column shard [col_begin, col_end) computed by this context; */
-  uint16_t col_end;            /*   0,0 means the whole width.  Multi-GPU: one context per rank. */
+  uint16_t col_begin;          /* pixel-column shard [col_begin, col_end) computed by this context; 0,0 means the whole width. */
+  uint16_t col_end;            /*   Leave 0,0 on a multi-device context / a rank context: the library assigns the tiles itself. */
 } atmrt_params_t;
 
 /* AtmosphereDef of crate atm-refraction 0.6 (schema: reference README.md:283-323): a pressure fixed point, a list of
  * temperature functions (the first from -inf, every next one from its `altitude` upwards), each either `Linear{gradient}`
- * or `Spline{boundary_condition, points}`, and — when every function is Linear — a temperature fixed point. */
-#define ATMRT_MAX_ATM_FUNCTIONS 8
-#define ATMRT_MAX_SPLINE_POINTS 32
+ * or `Spline{boundary_condition, points}`, and — when every function is Linear — a temperature fixed point.  Both lists are
+ * `Vec`s in the reference (params.rs:453-454) and unbounded here: pointer + count, borrowed for the duration of the call that
+ * takes the definition (atmrt_set_atmosphere copies what it needs). */
 typedef enum atmrt_temp_function_kind { ATMRT_TEMP_LINEAR = 0, ATMRT_TEMP_SPLINE = 1 } atmrt_temp_function_kind;
 typedef enum atmrt_spline_boundary {
   ATMRT_SPLINE_NATURAL = 0,            /* second derivative 0 at both ends */
@@ -118,10 +118,10 @@ typedef struct atmrt_temp_function {
   double altitude;   /* applies for h >= altitude; ignored for the first function */
   double gradient;   /* Linear: dT/dh [K/m] */
   double bc[2];      /* Spline boundary values */
-  int32_t n_points;  /* Spline: 2..ATMRT_MAX_SPLINE_POINTS, strictly increasing altitudes */
+  int32_t n_points;  /* Spline: >= 2, strictly increasing altitudes */
   int32_t _pad;
-  double point_altitude[ATMRT_MAX_SPLINE_POINTS];
-  double point_temperature[ATMRT_MAX_SPLINE_POINTS];
+  const double* point_altitude;    /* [n_points] */
+  const double* point_temperature; /* [n_points] */
 } atmrt_temp_function_t;
 typedef struct atmrt_atmosphere {
   double pressure_altitude;          /* pressure fixed point */
@@ -129,8 +129,8 @@ typedef struct atmrt_atmosphere {
   double temperature_altitude;       /* temperature_fixed_point (used only when has_temperature_fixed_point) */
   double temperature;                /* [K] */
   int32_t has_temperature_fixed_point;
-  int32_t n_functions;               /* 1..ATMRT_MAX_ATM_FUNCTIONS */
-  atmrt_temp_function_t functions[ATMRT_MAX_ATM_FUNCTIONS];
+  int32_t n_functions;               /* >= 1 */
+  const atmrt_temp_function_t* functions; /* [n_functions] */
 } atmrt_atmosphere_t;
 
 /* Scene objects, src/object/mod.rs:19-75,119-131 after ConfShape::into_shape. */
@@ -216,7 +216,7 @@ int atmrt_terrain_get_elev(atmrt_ctx* ctx, size_t n, const double* lat, const do
 
 /* ---- configuration ------------------------------------------------------------------------ */
 void atmrt_params_default(atmrt_params_t* p);         /* Config::default, params.rs:481-494 */
-void atmrt_atmosphere_us76(atmrt_atmosphere_t* a);    /* AtmosphereDef::us_76 */
+void atmrt_atmosphere_us76(atmrt_atmosphere_t* a);    /* AtmosphereDef::us_76; `functions` points at a table inside the library */
 int atmrt_set_params(atmrt_ctx* ctx, const atmrt_params_t* p);
 int atmrt_set_atmosphere(atmrt_ctx* ctx, const atmrt_atmosphere_t* a);
 /* scene.objects, in order (object/mod.rs:156-190).  Billboard textures are copied during the call. */
@@ -315,6 +315,74 @@ int atmrt_coloring_from_conf(const atmrt_params_t* params, int32_t kind, double 
 int atmrt_draw_image(atmrt_ctx* ctx, const atmrt_coloring_t* coloring, uint8_t* rgb);
 /* Same, into caller-provided device memory (3 B per pixel instead of 88 B per pixel to gather across GPUs). */
 int atmrt_draw_image_device(atmrt_ctx* ctx, const atmrt_coloring_t* coloring, uint8_t* rgb_device);
+
+/* ---- several GPUs of one node --------------------------------------------------------------------------------
+ * The reference calls `generator.generate()` ONCE per frame (src/generator/mod.rs:72-86, trait at generators/mod.rs:82-84), so the
+ * multi-GPU path lives BELOW this ABI: pixels are independent (rectilinear.rs:32-37), the image is cut into pixel-column tiles —
+ * device / rank g of G computes columns [g W / G, (g + 1) W / G) of every row against its own copy of the terrain mosaic — and the
+ * only exchange is the finished frame.  Two ways to get there, same code underneath:
+ *
+ *  (1) ONE PROCESS, SEVERAL DEVICES: atmrt_ctx_create_multi(devices, n) returns a context that every entry point of this header
+ *      accepts.  Each device gets a sub-context and a host thread.  atmrt_generate returns the whole [H][W] frame in host memory:
+ *      every device copies its tile straight into the one page-locked block (strided device-to-host copies over its own PCIe
+ *      link; no collective, the consumer being the host).  atmrt_generate_image_device leaves the whole frame in the HBM of EVERY
+ *      device: one ncclAllGather (RCCL over xGMI) of the tiles' planes + a permutation kernel into the [H][W] planes.
+ *  (2) ONE PROCESS PER GPU (torchrun, MPI): every rank creates a plain context, rank 0 obtains atmrt_comm_unique_id and hands it to
+ *      the others through whatever the launcher offers, every rank calls atmrt_ctx_comm_init_rank; atmrt_generate_image_device is
+ *      then collective over the ranks.  atmrt_generate / atmrt_generate_device on such a context return the rank's own tile.
+ *
+ * Frames whose pixels hold several trace points (terrain_alpha < 1, scene objects, InterpolatingRectilinear) also exchange the
+ * variable-length lists: atmrt_image_hits_device (count -> scan -> offset on the device, one all-gather of the lists). */
+#define ATMRT_COMM_ID_BYTES 128
+/* ncclGetUniqueId: 128 opaque bytes for the other ranks' atmrt_ctx_comm_init_rank. */
+int atmrt_comm_unique_id(uint8_t id[ATMRT_COMM_ID_BYTES]);
+/* Joins this context (one device) to `world` ranks that share every frame from now on: ncclCommInitRank, collective over the
+ * ranks.  Parameters keep describing the WHOLE image (col_begin = col_end = 0). */
+int atmrt_ctx_comm_init_rank(atmrt_ctx* ctx, const uint8_t id[ATMRT_COMM_ID_BYTES], int32_t rank, int32_t world);
+/* The same with the host's own transport in place of RCCL (an MPI all-gather without GPU awareness, a shared-memory ring, gloo,
+ * a test double): the callback must deliver, on every rank, rank i's `bytes_per_rank` bytes at recv_host + i * bytes_per_rank and
+ * return 0.  Both pointers are page-locked HOST memory owned by the library, which stages the tile out of and the gathered
+ * tiles back into HBM around the call. */
+typedef int (*atmrt_all_gather_fn)(void* user, const void* send_host, void* recv_host, size_t bytes_per_rank);
+int atmrt_ctx_comm_init_external(atmrt_ctx* ctx, int32_t rank, int32_t world, atmrt_all_gather_fn all_gather, void* user);
+/* One context over n_devices HIP devices of this process (1): terrain, parameters, atmosphere and objects set on it reach every
+ * device.  A device may be listed more than once (its tiles then are exchanged by device-to-device copies; RCCL needs distinct
+ * devices).  ATMRT_GATHER=peer forces that route, ATMRT_GATHER=rccl makes a failure to set RCCL up an error instead of a fallback. */
+int atmrt_ctx_create_multi(atmrt_ctx** out, const int32_t* devices, int32_t n_devices);
+/* 1 for a plain context, n_devices for a multi-device one. */
+int atmrt_ctx_device_count(const atmrt_ctx* ctx);
+/* Generator::generate with the WHOLE frame left in HBM: `image` holds one set of [H][W] planes per device of the context (a plain
+ * or rank context: one; a multi-device context: device_count sets, entry i in the memory of devices[i]; a set whose azimuth
+ * pointer is NULL is skipped).  ray_steps: of this rank (rank context) / of all devices (multi-device context). */
+int atmrt_generate_image_device(atmrt_ctx* ctx, const atmrt_device_planes_t* image, uint64_t* ray_steps, double* device_ms);
+/* The complete trace-point lists of that frame in the image's pixel order p = y W + x — atmrt_last_hits_device for the whole
+ * image — on every device: `dst` like `image` above (entry i on devices[i]; hit_offset is [H][W]).  dst == NULL only queries
+ * *n_hits (still collective).  Frames without lists (opaque terrain, no objects, not InterpolatingRectilinear): ATMRT_ERR_STATE. */
+int atmrt_image_hits_device(atmrt_ctx* ctx, const atmrt_device_hits_t* dst, uint64_t* n_hits);
+/* renderer::draw_image of every tile + an all-gather of the 3 B/pixel RGB8 tiles instead of the 84 B/pixel planes: rgb_device[i]
+ * is [H][W][3] on devices[i] (NULL entries skipped). */
+int atmrt_draw_image_gathered_device(atmrt_ctx* ctx, const atmrt_coloring_t* coloring, uint8_t* const* rgb_device);
+/* What the exchange of the last atmrt_generate_image_device / atmrt_generate (multi-device) cost, from HIP events on the
+ * library's streams (slowest device). */
+typedef enum atmrt_gather_route {
+  ATMRT_ROUTE_NONE = 0,     /* one device: nothing to exchange */
+  ATMRT_ROUTE_RCCL = 1,     /* ncclAllGather over xGMI */
+  ATMRT_ROUTE_PEER = 2,     /* device-to-device copies inside one process */
+  ATMRT_ROUTE_EXTERNAL = 3, /* the host's transport (atmrt_ctx_comm_init_external) */
+  ATMRT_ROUTE_HOST = 4      /* atmrt_generate on a multi-device context: strided copies into the host block */
+} atmrt_gather_route;
+typedef struct atmrt_comm_timings {
+  double gather_ms;         /* the collective (or the copies) */
+  double assemble_ms;       /* permutation of the gathered tiles into the [H][W] planes */
+  double tile_ms_max;       /* slowest device's generate time */
+  double tile_ms_min;       /* fastest device's */
+  uint64_t bytes_per_rank;  /* what each rank contributed to the collective */
+  int32_t world;
+  int32_t route;            /* atmrt_gather_route */
+  int32_t collectives;      /* data-path collectives of the last frame (1 for an image, + 2 for its lists) */
+  int32_t _pad;
+} atmrt_comm_timings_t;
+int atmrt_last_comm_timings(atmrt_ctx* ctx, atmrt_comm_timings_t* out);
 
 /* ---- integrator / sampler harnesses (the reference's diagnostic subcommands) ---------------- */
 /* output-ray-paths (src/ray_path.rs:65-103): for each elevation angle [deg] step the ray n_steps

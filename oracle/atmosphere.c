@@ -18,6 +18,7 @@
 #include "oracle.h"
 #include "oracle_math.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #define G0 9.80665
@@ -27,6 +28,7 @@
 void oracle_atmosphere_us76(atmrt_atmosphere_t* a) {
   static const double alt[7] = {0.0, 11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0};
   static const double lapse[7] = {-0.0065, 0.0, 0.001, 0.0028, 0.0, -0.0028, -0.002};
+  static atmrt_temp_function_t fns[7];
   int k;
   memset(a, 0, sizeof *a);
   a->pressure_altitude = 0.0;
@@ -35,11 +37,12 @@ void oracle_atmosphere_us76(atmrt_atmosphere_t* a) {
   a->temperature = 288.15;
   a->has_temperature_fixed_point = 1;
   a->n_functions = 7;
-  for (k = 0; k < 7; k++) {
-    a->functions[k].kind = ATMRT_TEMP_LINEAR;
-    a->functions[k].altitude = alt[k];
-    a->functions[k].gradient = lapse[k];
+  for (k = 0; k < 7; k++) { /* the same values on every call: safe to rewrite */
+    fns[k].kind = ATMRT_TEMP_LINEAR;
+    fns[k].altitude = alt[k];
+    fns[k].gradient = lapse[k];
   }
+  a->functions = fns;
 }
 
 static int layer_of(const oracle_env_atm* a, double h) {
@@ -86,7 +89,8 @@ static void spline_second_derivatives(const atmrt_temp_function_t* fn, double* m
   const int np = fn->n_points;
   const double* x = fn->point_altitude;
   const double* y = fn->point_temperature;
-  double cp[ATMRT_MAX_SPLINE_POINTS], dp[ATMRT_MAX_SPLINE_POINTS];
+  double* cp = (double*)malloc(2 * (size_t)np * sizeof(double));
+  double* dp = cp + np;
   double b0, c0, d0, an, bn, dn;
   int i;
   if (fn->boundary == ATMRT_SPLINE_DERIVATIVES) {
@@ -114,15 +118,35 @@ static void spline_second_derivatives(const atmrt_temp_function_t* fn, double* m
   }
   m[np - 1] = dp[np - 1];
   for (i = np - 2; i >= 0; i--) m[i] = dp[i] - cp[i] * m[i + 1];
+  free(cp);
+}
+
+void oracle_atm_free(oracle_env_atm* a) {
+  free(a->hb); /* one block: see oracle_atm_compile */
+  free(a->cubic);
+  memset(a, 0, sizeof *a);
 }
 
 int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_env_atm* out) {
   const double gmr = G0 * M_AIR / R_GAS;
   const int nf = def->n_functions;
   int n = 0, j, k, pass, any = 0, jp;
-  int first_seg[ATMRT_MAX_ATM_FUNCTIONS + 1], anchored[ATMRT_MAX_ATM_FUNCTIONS];
-  if (nf < 1 || nf > ATMRT_MAX_ATM_FUNCTIONS) return -1;
+  int *first_seg, *anchored;
+  size_t cap = 0;
+  double* m = NULL;
   memset(out, 0, sizeof *out);
+  if (nf < 1 || !def->functions) return -1;
+  for (j = 0; j < nf; j++) { /* a Linear function is one segment, a Spline at most its knot intervals + two continuations */
+    const atmrt_temp_function_t* fn = &def->functions[j];
+    if (fn->kind == ATMRT_TEMP_SPLINE && (fn->n_points < 2 || !fn->point_altitude || !fn->point_temperature)) return -4;
+    cap += fn->kind == ATMRT_TEMP_SPLINE ? (size_t)fn->n_points + 1 : 1;
+  }
+  out->hb = (double*)calloc(8 * cap, sizeof(double));
+  out->tb = out->hb + cap, out->pb = out->tb + cap, out->lapse = out->pb + cap, out->from = out->lapse + cap;
+  out->expo = out->from + cap, out->c2 = out->expo + cap, out->c3 = out->c2 + cap;
+  out->cubic = (int*)calloc(cap + 2 * ((size_t)nf + 1), sizeof(int));
+  first_seg = out->cubic + cap; /* scratch behind the segment flags, released with them */
+  anchored = first_seg + nf + 1;
   for (j = 2; j < nf; j++)
     if (!(def->functions[j].altitude > def->functions[j - 1].altitude)) return -2;
   for (j = 0; j < nf; j++) {
@@ -132,26 +156,30 @@ int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_
     first_seg[j] = n;
     anchored[j] = 0;
     if (fn->kind == ATMRT_TEMP_LINEAR) {
-      if (n >= ORACLE_MAX_SEGMENTS) return -5;
       out->from[n] = lo;
       out->lapse[n] = fn->gradient;
       n++;
       continue;
     }
-    if (fn->kind != ATMRT_TEMP_SPLINE) return -1;
+    if (fn->kind != ATMRT_TEMP_SPLINE) {
+      free(m);
+      return -1;
+    }
     {
       const int np = fn->n_points;
       const double* x = fn->point_altitude;
       const double* y = fn->point_temperature;
-      double m[ATMRT_MAX_SPLINE_POINTS];
       int i;
-      if (np < 2 || np > ATMRT_MAX_SPLINE_POINTS) return -4;
       for (i = 1; i < np; i++)
-        if (!(x[i] > x[i - 1])) return -4;
+        if (!(x[i] > x[i - 1])) {
+          free(m);
+          return -4;
+        }
+      free(m);
+      m = (double*)malloc((size_t)np * sizeof(double));
       spline_second_derivatives(fn, m);
       if (!has_lo || lo < x[0]) { /* linear continuation below the first knot, slope S'(x0) */
         double hh = x[1] - x[0];
-        if (n >= ORACLE_MAX_SEGMENTS) return -5;
         out->from[n] = lo;
         out->hb[n] = x[0];
         out->tb[n] = y[0];
@@ -162,7 +190,6 @@ int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_
         double hh;
         if (has_hi && x[i] >= hi) break;
         if (has_lo && x[i + 1] <= lo) continue;
-        if (n >= ORACLE_MAX_SEGMENTS) return -5;
         hh = x[i + 1] - x[i];
         out->from[n] = (has_lo && lo > x[i]) ? lo : x[i];
         out->hb[n] = x[i];
@@ -175,7 +202,6 @@ int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_
       }
       if (!has_hi || hi > x[np - 1]) { /* linear continuation above the last knot, slope S'(x_last) */
         double hh = x[np - 1] - x[np - 2];
-        if (n >= ORACLE_MAX_SEGMENTS) return -5;
         out->from[n] = x[np - 1];
         out->hb[n] = x[np - 1];
         out->tb[n] = y[np - 1];
@@ -185,6 +211,7 @@ int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_
       anchored[j] = 1;
     }
   }
+  free(m);
   first_seg[nf] = n;
   out->n = n;
   out->from[0] = 0.0;

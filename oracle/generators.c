@@ -811,7 +811,10 @@ int oracle_generate(const atmrt_params_t* params, const atmrt_atmosphere_t* atm,
   memset(&g, 0, sizeof g);
   g.params = params;
   g.terrain = terrain;
-  if (oracle_atm_compile(atm, params->wavelength, &g.atm)) return -1;
+  if (oracle_atm_compile(atm, params->wavelength, &g.atm)) {
+    oracle_atm_free(&g.atm);
+    return -1;
+  }
   g.spherical = oracle_to_shape(&params->earth, &g.radius);
   /* Altitude::abs, params.rs:23-30 */
   g.alt = params->position.altitude_kind == ATMRT_ALT_ABSOLUTE
@@ -832,7 +835,7 @@ int oracle_generate(const atmrt_params_t* params, const atmrt_atmosphere_t* atm,
       o->r1 = s->r1; o->r2 = s->r2; o->height = s->height; o->width = s->width;
       memcpy(o->color, s->color, sizeof o->color);
       o->tex = s->texture_rgba; o->tex_w = s->texture_width; o->tex_h = s->texture_height;
-      if (o->kind == ATMRT_OBJ_BILLBOARD && (!o->tex || o->tex_w < 2 || o->tex_h < 2)) { free(objs); return -1; }
+      if (o->kind == ATMRT_OBJ_BILLBOARD && (!o->tex || o->tex_w < 2 || o->tex_h < 2)) { free(objs); oracle_atm_free(&g.atm); return -1; }
     }
   }
   g.objects = objs;
@@ -891,6 +894,7 @@ int oracle_generate(const atmrt_params_t* params, const atmrt_atmosphere_t* atm,
   }
   free(px);
   free(objs);
+  oracle_atm_free(&g.atm);
   return 0;
 }
 
@@ -908,7 +912,10 @@ int oracle_ray_paths(const atmrt_params_t* params, const atmrt_atmosphere_t* atm
   double radius;
   int spherical = oracle_to_shape(&params->earth, &radius);
   size_t a, k;
-  if (oracle_atm_compile(atm, params->wavelength, &env)) return -1;
+  if (oracle_atm_compile(atm, params->wavelength, &env)) {
+    oracle_atm_free(&env);
+    return -1;
+  }
   for (a = 0; a < n_angles; a++) {
     oracle_stepper s;
     oracle_stepper_init(&s, &env, spherical, radius, h0, om_to_radians(angles_deg[a]), straight, step);
@@ -920,5 +927,6 @@ int oracle_ray_paths(const atmrt_params_t* params, const atmrt_atmosphere_t* atm
       h[a * (n_steps + 1) + k] = st.h;
     }
   }
+  oracle_atm_free(&env);
   return 0;
 }

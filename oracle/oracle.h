@@ -24,23 +24,24 @@ extern "C" {
 typedef struct { double x, y, z; } ovec3;
 
 /* ---- atmosphere + refractive index (crate atm-refraction, absent) ------------------------- */
-#define ORACLE_MAX_SEGMENTS 64
-typedef struct { /* the atmosphere compiled into segments: T(h) = tb + c1 dh + c2 dh^2 + c3 dh^3, dh = h - hb */
+typedef struct { /* the atmosphere compiled into segments: T(h) = tb + c1 dh + c2 dh^2 + c3 dh^3, dh = h - hb.  Any number of
+                    segments (Vec in the reference, params.rs:453-454): the arrays are allocated by oracle_atm_compile */
   int n;
-  double hb[ORACLE_MAX_SEGMENTS];    /* reference altitude of the segment */
-  double tb[ORACLE_MAX_SEGMENTS];    /* temperature at hb */
-  double pb[ORACLE_MAX_SEGMENTS];    /* pressure at hb */
-  double lapse[ORACLE_MAX_SEGMENTS]; /* c1 */
-  double from[ORACLE_MAX_SEGMENTS];  /* segment k>=1 applies for h >= from[k] */
-  double expo[ORACLE_MAX_SEGMENTS];  /* linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R */
-  double c2[ORACLE_MAX_SEGMENTS];
-  double c3[ORACLE_MAX_SEGMENTS];
-  int cubic[ORACLE_MAX_SEGMENTS];    /* 1: a knot interval of a Spline temperature function */
-  double k_refr;                     /* (n-1) = k_refr * (p/T) / Z */
+  double* hb;    /* reference altitude of the segment */
+  double* tb;    /* temperature at hb */
+  double* pb;    /* pressure at hb */
+  double* lapse; /* c1 */
+  double* from;  /* segment k>=1 applies for h >= from[k] */
+  double* expo;  /* linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R */
+  double* c2;
+  double* c3;
+  int* cubic;    /* 1: a knot interval of a Spline temperature function */
+  double k_refr; /* (n-1) = k_refr * (p/T) / Z */
 } oracle_env_atm;
 
 void oracle_atmosphere_us76(atmrt_atmosphere_t* a);
-int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_env_atm* out);
+int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_env_atm* out); /* release with oracle_atm_free, also after a failure */
+void oracle_atm_free(oracle_env_atm* a);
 double oracle_atm_temperature(const oracle_env_atm* a, double h);
 double oracle_atm_pressure(const oracle_env_atm* a, double h);
 double oracle_n(const oracle_env_atm* a, double h);

@@ -7,8 +7,9 @@ using namespace atmrt;
 
 extern "C" {
 int ch_atm(const atmrt_atmosphere_t* def, double wavelength, size_t n, const double* h, double* t, double* p, double* nn, double* dn) {
-  AtmTable a;
-  if (atm_compile(*def, wavelength, a)) return -1;
+  AtmTableBuf buf;
+  if (atm_compile(*def, wavelength, buf)) return -1;
+  const AtmTable& a = buf.table();
   for (size_t i = 0; i < n; i++) { t[i] = atm_temperature(a, h[i]); p[i] = atm_pressure(a, h[i]); nn[i] = refr_n(a, h[i]); dn[i] = refr_dn(a, h[i]); }
   return 0;
 }
@@ -33,24 +34,25 @@ int ch_cart(const atmrt_earth_model_t* m, double lat, double lon, double elev, d
 // of the certificate: min T, max p/T, max |Z - 1| and max n over a dense sample of the interval
 int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, double radius, double step, int* n_seg, double* from,
                double* safe_lo, double* safe_hi, double* band2, double* min_t, double* max_pt, double* max_z_dev, double* max_n) {
-  AtmTable a;
-  if (atm_compile(*def, wavelength, a)) return -1;
+  AtmTableBuf buf;
+  if (atm_compile(*def, wavelength, buf)) return -1;
+  AtmTable& a = buf.table();
   atm_certify(a, spherical != 0, radius, step);
   *n_seg = a.n;
   band2[0] = a.alt_lo;
   band2[1] = a.alt_hi;
   for (int k = 0; k < a.n; k++) {
-    from[k] = a.from[k];
-    safe_lo[k] = a.safe_lo[k];
-    safe_hi[k] = a.safe_hi[k];
+    from[k] = a.seg(k).from;
+    safe_lo[k] = a.seg(k).safe_lo;
+    safe_hi[k] = a.seg(k).safe_hi;
     min_t[k] = 1e300; max_pt[k] = max_z_dev[k] = max_n[k] = 0.0;
-    if (!(a.safe_lo[k] < a.safe_hi[k])) continue;
+    if (!(a.seg(k).safe_lo < a.seg(k).safe_hi)) continue;
     const int N = 4000;
     for (int i = 0; i <= N; i++) {
-      double h = a.safe_lo[k] + (a.safe_hi[k] - a.safe_lo[k]) * i / N;
-      double t = atm_seg_temperature(a, k, h), pr = a.pb[k] * atm_pressure_ratio(a, k, h), pt = pr / t, c = t - 273.15;
+      double h = a.seg(k).safe_lo + (a.seg(k).safe_hi - a.seg(k).safe_lo) * i / N;
+      double t = atm_seg_temperature(a, k, h), pr = a.seg(k).pb * atm_pressure_ratio(a, k, h), pt = pr / t, c = t - 273.15;
       double z = 1.0 - pt * (1.58123e-6 + c * (-2.9331e-8 + c * 1.1043e-10)) + pt * pt * 1.83e-11;
-      double n = refr_n_layer(a.k_refr, a.cubic[k], a.hb[k], a.tb[k], a.pb[k], a.lapse[k], a.c2[k], a.c3[k], a.expo[k], h);
+      double n = refr_n_layer(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
       if (!(t >= min_t[k])) min_t[k] = t;
       if (!(pt <= max_pt[k])) max_pt[k] = pt;
       double zd = z > 1.0 ? z - 1.0 : 1.0 - z;
@@ -62,9 +64,10 @@ int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, 
 }
 int ch_ray_path(const atmrt_atmosphere_t* def, const atmrt_earth_model_t* m, double wavelength, double h0, double ang_deg, int straight,
                 double step, size_t n_steps, double* x, double* h) {
-  AtmTable a;
+  AtmTableBuf buf;
   Earth e;
-  if (atm_compile(*def, wavelength, a) || earth_resolve(*m, e)) return -1;
+  if (atm_compile(*def, wavelength, buf) || earth_resolve(*m, e)) return -1;
+  const AtmTable& a = buf.table();
   Stepper s;
   stepper_init(s, e.spherical != 0, e.shape_radius, h0, dm_to_radians(ang_deg));
   x[0] = 0.0; h[0] = h0;

@@ -22,8 +22,14 @@ class Vec3(C.Structure):
 
 
 class EnvAtm(C.Structure):
-    _fields_ = [("n", C.c_int)] + [(k, C.c_double * 64) for k in ("hb", "tb", "pb", "lapse", "from_", "expo", "c2", "c3")] + \
-        [("cubic", C.c_int * 64), ("k_refr", C.c_double)]
+    """oracle_env_atm: the arrays are allocated by oracle_atm_compile (any number of segments) and released by oracle_atm_free."""
+    _fields_ = [("n", C.c_int)] + [(k, C.POINTER(C.c_double)) for k in ("hb", "tb", "pb", "lapse", "from_", "expo", "c2", "c3")] + \
+        [("cubic", C.POINTER(C.c_int)), ("k_refr", C.c_double)]
+    _free = None
+
+    def __del__(self):
+        if self._free is not None and self.hb:
+            self._free(C.byref(self))
 
 
 class DirCalc(C.Structure):
@@ -54,6 +60,8 @@ class Oracle:
         L.oracle_set_row_filter.argtypes = [C.c_int, C.c_int]
         L.oracle_set_row_filter.restype = None
         L.oracle_atm_compile.argtypes = [C.POINTER(_abi.Atmosphere), C.c_double, C.POINTER(EnvAtm)]
+        L.oracle_atm_free.argtypes = [C.POINTER(EnvAtm)]
+        L.oracle_atm_free.restype = None
         for f in ("oracle_atm_temperature", "oracle_atm_pressure", "oracle_n", "oracle_dn"):
             getattr(L, f).argtypes = [C.POINTER(EnvAtm), C.c_double]
             getattr(L, f).restype = C.c_double
@@ -121,8 +129,10 @@ class Oracle:
 
     def env(self, atm=None, wavelength=530e-9):
         e = EnvAtm()
+        e._free = self.lib.oracle_atm_free
         atm = atm or self.us76()
         assert self.lib.oracle_atm_compile(C.byref(atm), wavelength, C.byref(e)) == 0
+        e._atm = atm  # nothing of `atm` is referenced by the compiled table; kept only so that callers may drop theirs
         return e
 
     def n(self, env, h):

@@ -29,7 +29,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_sizes_match_the_header(lib):
     for which, st in enumerate((_abi.Params, _abi.Atmosphere, _abi.Object, _abi.Result, _abi.DevicePlanes, _abi.EarthModel,
-                                _abi.Position, _abi.Frame, _abi.FrameStats, _abi.Timings, _abi.Coloring, _abi.DeviceHits)):
+                                _abi.Position, _abi.Frame, _abi.FrameStats, _abi.Timings, _abi.Coloring, _abi.DeviceHits, _abi.CommTimings,
+                                _abi.TempFunction)):
         assert lib.atmrt_abi_sizeof(which) == C.sizeof(st), st.__name__
 
 
@@ -43,7 +44,7 @@ def test_defaults_match_the_reference(lib):
     a = _abi.Atmosphere()
     lib.atmrt_atmosphere_us76(C.byref(a))
     assert a.n_functions == 7 and a.pressure == 101325.0 and a.temperature == 288.15 and a.functions[0].gradient == -0.0065
-    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 3
+    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 4
 
 
 def test_no_cpu_fallback(lib):
@@ -53,6 +54,8 @@ def test_no_cpu_fallback(lib):
     h = C.c_void_p()
     assert lib.atmrt_ctx_create(C.byref(h), 0) == _abi.ERR_NO_DEVICE
     assert b"no CPU path" in lib.atmrt_last_error(None)
+    devices = (C.c_int32 * 2)(0, 1)
+    assert lib.atmrt_ctx_create_multi(C.byref(h), devices, 2) == _abi.ERR_NO_DEVICE and not h.value
     from atm_raytracer_amd import generators
     with pytest.raises(_lib.AtmrtError):
         generators.Context(0)

@@ -117,3 +117,70 @@ def test_gpu_parity_with_spline_atmosphere(gpu_ctx, oracle_det, generator, w, h)
     assert got["n_hits"] > 0
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
     gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(config.us76())))
+
+
+# ---- unbounded definitions: `next_functions` and a Spline's `points` are Vecs in the reference (README.md:283-323, params.rs:453-454).
+# Until ABI 4 the C ABI held at most 8 functions / 32 knots / 64 compiled segments; a radiosonde-derived spline has more knots.
+def radiosonde_spline(n_knots=200, top=30_000.0, seed=11):
+    """A sounding-like profile: a knot every ~150 m up to 30 km, the standard lapse structure + inversions and noise."""
+    rng = np.random.default_rng(seed)
+    alt = np.sort(np.concatenate([[0.0, top], rng.uniform(20.0, top - 20.0, n_knots - 2)]))
+    alt += np.arange(n_knots) * 1e-3  # strictly increasing
+    std = np.where(alt < 11000.0, 288.15 - 0.0065 * alt, np.where(alt < 20000.0, 216.65, 216.65 + 0.001 * (alt - 20000.0)))
+    temp = std + 1.5 * np.sin(alt / 700.0) + rng.normal(0.0, 0.15, n_knots) + 4.0 * np.exp(-((alt - 900.0) / 250.0) ** 2)
+    return {"pressure": {"altitude": 120.0, "pressure": 100_150.0},
+            "first_temperature_function": {"Spline": {"boundary_condition": "Natural", "points": [[float(a), float(t)] for a, t in zip(alt, temp)]}}}
+
+
+def forty_linear_layers():
+    """40 Linear layers 400 m thick with alternating lapse rates, continued by an isothermal layer: 41 temperature functions."""
+    grads = [(-0.0095 if k % 2 == 0 else -0.0035) if k < 28 else (0.0 if k % 3 else 0.0015) for k in range(40)]
+    return {"pressure": {"altitude": 0.0, "pressure": 101_000.0}, "temperature_fixed_point": {"altitude": 0.0, "temperature": 290.0},
+            "first_temperature_function": {"Linear": {"gradient": grads[0]}},
+            "next_functions": [{"altitude": 400.0 * k, "function": {"Linear": {"gradient": g}}} for k, g in enumerate(grads) if k > 0] +
+                              [{"altitude": 16_000.0, "function": {"Linear": {"gradient": 0.0}}}]}
+
+
+BIG_ATMOSPHERES = {"spline-200-knots": radiosonde_spline, "linear-41-functions": forty_linear_layers}
+
+
+@pytest.mark.parametrize("name", sorted(BIG_ATMOSPHERES))
+def test_big_atmospheres_compile_identically_in_product_and_oracle(oracle_det, name):
+    """The product's host code (atm_compile with its bisection atm_layer) against the oracle (linear search) on atmospheres far
+    beyond the old capacities: T, p, n and dn/dh identical to the last bit at 6000 altitudes incl. every boundary."""
+    core = C.CDLL(cbuild.core_host())
+    a = config._atmosphere(BIG_ATMOSPHERES[name]())
+    assert (a.n_functions == 1 and a.functions[0].n_points == 200) or a.n_functions == 41
+    env = oracle_det.env(a, 530e-9)
+    assert env.n >= 41
+    edges = np.array([env.from_[k] for k in range(env.n)])
+    h = np.concatenate([np.linspace(-400.0, 33_000.0, 5000), edges, np.nextafter(edges, -np.inf), edges + 0.004, [np.nan, -1e9, 1e9]])
+    t, p, n, dn = (np.empty_like(h) for _ in range(4))
+    ptr = lambda x: C.c_void_p(x.ctypes.data)
+    assert core.ch_atm(C.byref(a), C.c_double(530e-9), C.c_size_t(h.size), ptr(h), ptr(t), ptr(p), ptr(n), ptr(dn)) == 0
+    same = lambda x, y: x == y or (x != x and y != y)
+    for i, hi in enumerate(h):
+        assert same(t[i], oracle_det.temperature(env, hi)) and same(p[i], oracle_det.pressure(env, hi)), hi
+        assert same(n[i], oracle_det.n(env, hi)) and same(dn[i], oracle_det.dn(env, hi)), hi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(BIG_ATMOSPHERES))
+@pytest.mark.parametrize("generator,w,h", [("Fast", 96, 48), ("Rectilinear", 40, 24), ("InterpolatingRectilinear", 72, 40)])
+def test_gpu_parity_with_big_atmospheres(gpu_ctx, oracle_det, name, generator, w, h):
+    """A 200-knot Spline and 41 Linear functions through all three generators on the GPU, bit-exact against the oracle; the
+    sampler harness too (every segment is visited)."""
+    atm = config._atmosphere(BIG_ATMOSPHERES[name]())
+    cfg, tiles = synth.scene("S2", w, h, generator=generator, tilt=-0.5, fov=30.0, max_distance=90_000.0)
+    cfg.atmosphere = atm
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert got["n_hits"] > 0
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+    from atm_raytracer_amd import generators
+    env = oracle_det.env(atm, cfg.params.wavelength)
+    alt = np.linspace(-300.0, 32_000.0, 3001)
+    s = generators.atmosphere_sample(gpu_ctx, alt)
+    for i in range(0, alt.size, 7):
+        assert s["temperature"][i] == oracle_det.temperature(env, alt[i]) and s["n"][i] == oracle_det.n(env, alt[i])
+        assert s["pressure"][i] == oracle_det.pressure(env, alt[i]) and s["dn_dh"][i] == oracle_det.dn(env, alt[i])
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(config.us76())))

@@ -88,4 +88,4 @@ def test_spline_temperature_function_from_the_readme():
     assert a.n_functions == 2 and a.has_temperature_fixed_point == 0
     f = a.functions[1]
     assert (f.kind, f.boundary, f.n_points, f.altitude) == (_abi.TEMP_SPLINE, _abi.SPLINE_BOUNDARY["Derivatives"], 3, 100.0)
-    assert list(f.bc) == [-0.0065, 0.0] and list(f.point_temperature)[:3] == [288.0, 285.0, 291.0]
+    assert list(f.bc) == [-0.0065, 0.0] and f.point_temperature[:3] == [288.0, 285.0, 291.0]

@@ -106,7 +106,8 @@ WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
 
 def _certify(core, atm, spherical=True, radius=6371000.0, step=50.0, wavelength=530e-9):
     n = C.c_int(0)
-    arrs = [np.zeros(64) for _ in range(7)]
+    cap = sum(atm.functions[j].n_points + 1 if atm.functions[j].kind == 1 else 1 for j in range(atm.n_functions))  # most segments the table can have
+    arrs = [np.zeros(cap) for _ in range(7)]
     band = np.zeros(2)
     assert core.ch_certify(C.byref(atm), C.c_double(wavelength), int(spherical), C.c_double(radius), C.c_double(step), C.byref(n),
                            ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(band), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(arrs[6])) == 0

@@ -1,0 +1,244 @@
+"""The multi-GPU path below the C ABI (csrc/atmrt_multi.hip), rehearsed on the ONE GPU of the test box: a device may be
+listed more than once in atmrt_ctx_create_multi, so [0, 0, 0] is three sub-contexts with three host threads that cut every frame
+into three pixel-column tiles — exactly the code an 8-GPU node runs, with device-to-device copies in place of xGMI.  RCCL refuses
+two ranks on one device, so its route runs at world size 1 (same calls: ncclCommInitAll / ncclCommInitRank, ncclAllGather).
+
+The bar: what a multi-device context returns IS the single-context frame — every plane, every trace point, every offset,
+bit for bit, for all three generators, with and without variable-length lists, also when the width does not divide."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from atm_raytracer_amd import _abi, generators, synth
+from util import assert_bitexact, bits, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+GENERATORS = ["Fast", "Rectilinear", "InterpolatingRectilinear"]
+
+
+def scene(generator, lists, width=96, height=40):
+    """A small S2 frame; `lists`: translucent terrain + a few objects, so pixels hold several trace points."""
+    kw = dict(terrain_alpha=0.5, tilt=-4.0) if lists else {}
+    cfg, tiles = synth.scene("S2", width, height, generator=generator, max_distance=60_000.0, **kw)
+    if lists:
+        synth.add_objects(cfg, n_cyl=14, n_bill=6, dist=(1_000.0, 40_000.0), spread_deg=25.0)
+    return cfg, tiles
+
+
+def dense_first_hits(res):
+    """What atmrt_generate_device leaves in the planes: the first trace point of every pixel, NaN where there is none."""
+    hc = res["hit_count"]
+    first = res["hit_offset"].astype(np.int64)
+    has = hc > 0
+    out = {"azimuth": res["azimuth"], "elevation_angle": res["elevation_angle"], "hit_count": hc.astype(np.int32)}
+    for k in ("lat", "lon", "distance", "elevation", "path_length"):
+        plane = np.full(hc.shape, np.nan)
+        plane[has] = res[k][first[has]]
+        out[k] = plane
+    nrm = np.full((3,) + hc.shape, np.nan)
+    for c in range(3):
+        nrm[c][has] = res["normal"][first[has], c]
+    out["normal"] = nrm
+    return out
+
+
+def check_image(planes, want):
+    ref = dense_first_hits(want)
+    for k, v in ref.items():
+        got = planes[k].cpu().numpy()
+        assert got.shape == v.shape, k
+        if k == "hit_count":
+            assert np.array_equal(got, v), k
+            continue
+        g, w = bits(got), bits(v)
+        if k not in ("azimuth", "elevation_angle"):  # planes are only defined where the pixel has a trace point
+            sel = np.broadcast_to(ref["hit_count"] > 0, v.shape)
+            g, w = g[sel], w[sel]
+        assert np.array_equal(g, w), (k, int((g != w).sum()))
+
+
+def check_lists(hits, want):
+    assert np.array_equal(hits["hit_offset"].cpu().numpy().astype(np.uint64), want["hit_offset"])
+    for k in ("lat", "lon", "distance", "elevation", "path_length", "normal", "rgba"):
+        assert np.array_equal(bits(hits[k].cpu().numpy()), bits(want[k])), k
+    assert np.array_equal(hits["color_tag"].cpu().numpy().astype(np.uint32), want["color_tag"])
+
+
+@pytest.fixture(scope="module")
+def multi3():
+    ctx = generators.Context.multi([0, 0, 0])
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("lists", [False, True], ids=["opaque", "lists"])
+@pytest.mark.parametrize("generator", GENERATORS)
+def test_multi_context_host_frame_is_the_single_context_frame(gpu_ctx, multi3, generator, lists):
+    """atmrt_generate on three sub-contexts: tiles of 33 / 34 / 34 columns (101 does not divide), planes copied straight into the
+    one [H][W] block, lists merged row segment by row segment."""
+    cfg, tiles = scene(generator, lists, width=101, height=37)
+    want = run_gpu(gpu_ctx, cfg, tiles)
+    got = run_gpu(multi3, cfg, tiles)
+    assert got["hit_count"].shape == (37, 101) and want["n_hits"] > 0
+    if lists:
+        assert want["hit_count"].max() > 1 and (want["color_tag"] == 1).any()
+    if generator == "InterpolatingRectilinear":
+        # every tile computes its own angular lattice, so lattice pixels along a tile boundary are marched by both neighbours: the
+        # image is identical, the work is slightly more (ray_steps counts the lattice pixels a tile references)
+        assert want["ray_steps"] <= got["ray_steps"] <= 1.2 * want["ray_steps"]
+        got["ray_steps"] = want["ray_steps"]
+    assert_bitexact(got, want)
+    tm = multi3.comm_timings()
+    assert tm["world"] == 3 and tm["route"] == "host"
+    # renderer compositing of the tiles into one host image
+    conf = dict(kind=_abi.COLORING_SHADING, water_level=0.0, ambient_light=0.4, light_zenith_angle=45.0, light_dir=0.0,
+                palette=_abi.PALETTES["Improved"], has_fog=1, fog_distance=40_000.0)
+    col = generators.into_coloring(gpu_ctx.lib, cfg.params, conf)
+    run_gpu(gpu_ctx, cfg, tiles)
+    assert np.array_equal(generators.draw_image(multi3, col, 101, 37), generators.draw_image(gpu_ctx, col, 101, 37))
+
+
+def make_ctx(kind):
+    if kind == "peer-2":
+        return generators.Context.multi([0, 0])
+    if kind == "peer-5":
+        return generators.Context.multi([0] * 5)
+    if kind == "rccl-multi-1":
+        return generators.Context.multi([0])
+    if kind == "rccl-rank-1":
+        ctx = generators.Context(0)
+        ctx.comm_init_rank(ctx.comm_unique_id(), 0, 1)
+        return ctx
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["peer-2", "peer-5", "rccl-multi-1", "rccl-rank-1"])
+def test_image_in_hbm_on_every_device(gpu_ctx, kind):
+    """atmrt_generate_image_device + atmrt_image_hits_device + atmrt_draw_image_gathered_device: slab all-gather (RCCL, or peer
+    copies between sub-contexts of one device), permutation into [H][W] planes, count -> scan -> offset for the lists."""
+    ctx = make_ctx(kind)
+    n_dev = len(ctx.devices)
+    try:
+        for generator in GENERATORS:
+            for lists in (False, True):
+                cfg, tiles = scene(generator, lists, width=90 if n_dev != 5 else 93, height=33)
+                W, H = cfg.params.width, cfg.params.height
+                want = run_gpu(gpu_ctx, cfg, tiles)
+                ctx.check(ctx.lib.atmrt_terrain_clear(ctx.handle))
+                gen = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, ctx))
+                images = [generators.image_planes(H, W, torch.device("cuda", 0)) for _ in range(n_dev)]
+                steps, _ = gen.generate_image_device([pod for _, pod in images])
+                assert steps == want["ray_steps"] or (generator == "InterpolatingRectilinear" and want["ray_steps"] <= steps <= 1.3 * want["ray_steps"])
+                for planes, _ in images:
+                    check_image(planes, want)
+                tm = ctx.comm_timings()
+                assert tm["world"] == n_dev and tm["route"] == ("rccl" if kind.startswith("rccl") else "peer") and tm["collectives"] == 1
+                if lists or generator == "InterpolatingRectilinear":
+                    hits = gen.image_hits_device(H, W)
+                    for h in (hits if isinstance(hits, list) else [hits]):
+                        check_lists(h, want)
+                    assert ctx.comm_timings()["collectives"] == 3
+                else:
+                    n = C.c_uint64()
+                    assert ctx.lib.atmrt_image_hits_device(ctx.handle, None, C.byref(n)) == _abi.ERR_STATE
+                # the 3 B/pixel route: draw every tile, gather the RGB8 tiles
+                conf = dict(kind=_abi.COLORING_SIMPLE, water_level=0.0, ambient_light=0.4, light_zenith_angle=45.0, light_dir=0.0,
+                            palette=_abi.PALETTES["Legacy"], has_fog=0, fog_distance=1.0)
+                col = generators.into_coloring(gpu_ctx.lib, cfg.params, conf)
+                rgbs = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0") for _ in range(n_dev)]
+                ptrs = (C.c_void_p * n_dev)(*[t.data_ptr() for t in rgbs])
+                ctx.check(ctx.lib.atmrt_draw_image_gathered_device(ctx.handle, C.byref(col), ptrs))
+                run_gpu(gpu_ctx, cfg, tiles)
+                ref = generators.draw_image(gpu_ctx, col, W, H)
+                for t in rgbs:
+                    assert np.array_equal(t.cpu().numpy(), ref)
+    finally:
+        ctx.close()
+
+
+def test_external_transport_two_ranks_in_two_threads(gpu_ctx):
+    """atmrt_ctx_comm_init_external: two rank contexts on the one GPU, driven by two host threads; the host's all-gather is a
+    test double (a barrier and a shared buffer).  The path an MPI or gloo host takes."""
+    world = 2
+    barrier = threading.Barrier(world)
+    shared = {}
+    lock = threading.Lock()
+
+    def transport(rank):
+        def all_gather(send, recv):
+            n = len(send)
+            with lock:
+                shared[rank] = bytes(send)
+            barrier.wait()
+            for r in range(world):
+                C.memmove(C.addressof(recv) + r * n, shared[r], n)
+            barrier.wait()
+            if rank == 0:
+                shared.clear()
+            barrier.wait()
+        return all_gather
+
+    cfg, tiles = scene("Rectilinear", True, width=70, height=30)
+    W, H = cfg.params.width, cfg.params.height
+    want = run_gpu(gpu_ctx, cfg, tiles)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            ctx = generators.Context(0)
+            ctx.comm_init_external(rank, world, transport(rank))
+            cfg_r, _ = scene("Rectilinear", True, width=70, height=30)
+            gen = generators.make_generator(generators.Params(cfg_r), generators.Terrain.from_tiles(tiles, ctx))
+            planes, pod = generators.image_planes(H, W, torch.device("cuda", 0))
+            steps, _ = gen.generate_image_device(pod)
+            hits = gen.image_hits_device(H, W)
+            results[rank] = (planes, hits, steps, ctx.comm_timings())
+            ctx.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert sum(results[r][2] for r in range(world)) == want["ray_steps"]
+    for r in range(world):
+        planes, hits, _, tm = results[r]
+        check_image(planes, want)
+        check_lists(hits, want)
+        assert tm["route"] == "external" and tm["world"] == 2
+
+
+def test_multi_context_errors_and_recovery(gpu_ctx, multi3):
+    cfg, tiles = scene("Fast", False, width=60, height=24)
+    # the library assigns the tiles: a caller's own column shard is refused
+    cfg.params.col_begin, cfg.params.col_end = 0, 30
+    assert multi3.lib.atmrt_set_params(multi3.handle, C.byref(cfg.params)) == _abi.ERR_INVALID_ARGUMENT
+    cfg.params.col_begin = cfg.params.col_end = 0
+    # fewer columns than devices
+    narrow, _ = scene("Fast", False, width=2, height=8)
+    with pytest.raises(generators.AtmrtError) as e:
+        run_gpu(multi3, narrow, tiles)
+    assert "less than" in str(e.value)
+    # a frame that fails on one device fails as a whole, names the device, and the context goes on
+    want = run_gpu(gpu_ctx, cfg, tiles)
+    multi3.check(multi3.lib.atmrt_debug_fail_next_frame(multi3.handle))
+    with pytest.raises(generators.AtmrtError) as e:
+        run_gpu(multi3, cfg, tiles)
+    assert "device" in str(e.value) and "injected" in str(e.value)
+    assert_bitexact(run_gpu(multi3, cfg, tiles), want)
+    # the device-only entry points of a plain context are refused on a multi-device one
+    planes, pod = generators.image_planes(24, 60, torch.device("cuda", 0))
+    assert multi3.lib.atmrt_generate_device(multi3.handle, C.byref(pod), None, None) == _abi.ERR_STATE
+    # the diagnostic entry points run on the first device
+    alt = np.array([0.0, 1000.0, 12000.0])
+    a, b = generators.atmosphere_sample(multi3, alt), generators.atmosphere_sample(gpu_ctx, alt)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert multi3.lib.atmrt_ctx_device_count(multi3.handle) == 3 and gpu_ctx.lib.atmrt_ctx_device_count(gpu_ctx.handle) == 1

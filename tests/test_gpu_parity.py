@@ -37,9 +37,9 @@ def test_sqrt_and_division_are_ieee(gpu_ctx):
 
 @pytest.mark.parametrize("generator", ["Fast", "Rectilinear"])
 def test_s1_flat_zero_terrain_straight(gpu_ctx, oracle_det, generator):
-    """BASELINE config 1: 256x128, straight rays, no terrain files (every lookup -> 0 m)."""
-    w, h = (256, 128) if generator == "Fast" else (64, 32)
-    cfg, tiles = synth.scene("S1", w, h, generator=generator)
+    """BASELINE config 1 at its stated size: 256x128, straight rays, no terrain files (every lookup -> 0 m)."""
+    cfg, tiles = synth.scene("S1", generator=generator)
+    assert (cfg.params.width, cfg.params.height) == (256, 128)
     assert_bitexact(run_gpu(gpu_ctx, cfg, tiles), run_oracle(oracle_det, cfg, tiles))
 
 
@@ -51,6 +51,29 @@ def test_s2_refraction_one_tile(gpu_ctx, oracle_det, oracle_libm, generator, w, 
     assert got["n_hits"] > 0
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
     assert_close(got, run_oracle(oracle_libm, cfg, tiles), RTOL)
+
+
+@pytest.mark.parametrize("generator", ["Fast", "Rectilinear", "InterpolatingRectilinear"])
+def test_s2_at_its_stated_size(gpu_ctx, oracle_det, oracle_libm, generator):
+    """BASELINE config 2 AS STATED: 1024x512, spherical Earth + US-76 refraction, one synthetic 1x1 degree DTED tile, 100 m steps
+    to 200 km.  The Fast oracle computes the whole frame; for the per-pixel generators it computes 24 columns spread over the
+    frame (column shards of the same frame).  Bit-exact vs the deterministic oracle, identical hit/miss + 1e-4 vs libm."""
+    from util import assert_columns_close, assert_columns_match
+    cfg, tiles = synth.scene("S2", generator=generator)
+    assert (cfg.params.width, cfg.params.height, cfg.params.simulation_step, cfg.params.frame.max_distance) == (1024, 512, 100.0, 200_000.0)
+    full = run_gpu(gpu_ctx, cfg, tiles)
+    assert full["hit_count"].shape == (512, 1024) and full["n_hits"] > 10_000
+    if generator == "Fast":
+        assert_bitexact(full, run_oracle(oracle_det, cfg, tiles))
+        assert_close(full, run_oracle(oracle_libm, cfg, tiles), RTOL)
+        return
+    n = 0
+    for c0 in range(3, 1024, 85):
+        shard = synth.scene("S2", generator=generator)[0]
+        shard.params.col_begin, shard.params.col_end = c0, c0 + 2
+        n += assert_columns_match(full, run_oracle(oracle_det, shard, tiles), c0)
+        assert_columns_close(full, run_oracle(oracle_libm, shard, tiles), c0, RTOL)
+    assert n > 500
 
 
 @pytest.mark.parametrize("earth", ["SimpleSphere", "Wgs84", {"Ellipsoid": {"a": 6378137.0, "b": 6356752.3}},

@@ -84,3 +84,31 @@ def assert_columns_match(full, want, c0, rows=None, x0=0):
         bad = np.flatnonzero((g != o).reshape(len(gi), -1).any(axis=1)) if len(gi) else np.zeros(0, int)
         assert bad.size == 0, f"{k}: {bad.size} of {len(gi)} trace points differ in columns {c0}..{c0 + w - 1}"
     return int(cnt.sum())
+
+
+def assert_columns_close(full, want, c0, rtol, rows=None, x0=0):
+    """The north-star statement against the oracle flavour that shares no numerics with the product (glibc libm, what Rust's
+    f64::sin etc. call): hit/miss and the number of trace points of every pixel of the columns IDENTICAL (a flip would be a
+    `diff1 * diff2 < 0` decided differently, utils.rs:222), azimuth / elevation angle and every trace-point field within rtol
+    relative.  Returns (trace points compared, worst relative difference seen in lat / lon / distance / elevation)."""
+    H, w = want["hit_count"].shape
+    ys = np.arange(H) if rows is None else np.arange(rows[1], H, rows[0])
+    cols = slice(c0 - x0, c0 - x0 + w)
+    flips = int((full["hit_count"][ys, cols] != want["hit_count"][ys]).sum())
+    assert flips == 0, f"{flips} pixels of columns {c0}..{c0 + w - 1} differ in hit/miss or trace-point count between the GPU and the libm oracle"
+    for k in ("azimuth", "elevation_angle"):
+        np.testing.assert_allclose(full[k][ys, cols], want[k][ys], rtol=rtol, atol=1e-9)
+    cnt = want["hit_count"][ys].astype(np.int64).ravel()
+    goff = np.repeat(full["hit_offset"][ys, cols].astype(np.int64).ravel(), cnt)
+    woff = np.repeat(want["hit_offset"][ys].astype(np.int64).ravel(), cnt)
+    within = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    gi, wi = goff + within, woff + within
+    worst = 0.0
+    for k in ("lat", "lon", "distance", "elevation", "path_length"):
+        g, o = full[k][gi], want[k][wi]
+        np.testing.assert_allclose(g, o, rtol=rtol, atol=1e-6, err_msg=k)
+        if k != "path_length" and len(gi):
+            worst = max(worst, float(np.max(np.abs(g - o) / np.maximum(np.abs(o), 1.0))))
+    np.testing.assert_allclose(full["normal"][gi], want["normal"][wi], rtol=rtol, atol=1e-7)
+    assert np.array_equal(full["color_tag"][gi], want["color_tag"][wi])
+    return int(cnt.sum()), worst

@@ -68,7 +68,7 @@ def test_s2_at_its_stated_size(gpu_ctx, oracle_det, oracle_libm, generator):
         assert_close(full, run_oracle(oracle_libm, cfg, tiles), RTOL)
         return
     n = 0
-    for c0 in range(3, 1024, 85):
+    for c0 in range(3, 1020, 85):
         shard = synth.scene("S2", generator=generator)[0]
         shard.params.col_begin, shard.params.col_end = c0, c0 + 2
         n += assert_columns_match(full, run_oracle(oracle_det, shard, tiles), c0)

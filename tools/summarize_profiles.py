@@ -93,7 +93,7 @@ def main():
 
     sq = defaultdict(dict)
     sq_launches = {}
-    for sub in ("sq1", "sq2"):
+    for sub in ("sq1", "sq2", "mix1", "mix2"):
         c, nl = counters(os.path.join(src, sub))
         for k, v in c.items():
             sq[k].update(v)
@@ -115,6 +115,20 @@ def main():
                 per_frame = sq_launches.get(k, 0) / frames[frag] if frames.get(frag) else 1.0  # a kernel launched in segments
                 v["launches_per_frame"] = per_frame
                 v["valu_lane_instructions_per_ray_step"] = v["SQ_INSTS_VALU"] * per_frame * 64.0 * v["lane_utilisation"] / n
+                if "SQ_INSTS_VALU_FMA_F64" in v:
+                    # The instruction mix (wave-instructions per launch -> lane-instructions per ray-step) and the FP64 FLOP count it
+                    # implies: an FMA is 2 flops, an add or a mul 1, a transcendental (v_rcp_f64, v_rsq_f64 ...) 1.  With
+                    # -ffp-contract=off the formulas of the reference compile to separate mul and add; FMAs come from detmath's
+                    # explicit fma() (polynomials, division / square-root refinement).
+                    scale = per_frame * 64.0 * v["lane_utilisation"] / n
+                    mix = {k2: v.get("SQ_INSTS_VALU_" + k2, 0.0) * scale for k2 in
+                           ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "INT32", "INT64", "CVT", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")}
+                    mix["other_moves_compares_selects"] = v["valu_lane_instructions_per_ray_step"] - sum(mix.values())
+                    v["lane_instructions_per_ray_step_by_kind"] = mix
+                    v["fp64_flops_per_ray_step"] = mix["ADD_F64"] + mix["MUL_F64"] + 2.0 * mix["FMA_F64"] + mix["TRANS_F64"]
+                    v["fp64_arith_lane_instructions_per_ray_step"] = mix["ADD_F64"] + mix["MUL_F64"] + mix["FMA_F64"] + mix["TRANS_F64"]
+                    if "SQ_INSTS_VALU_FLOPS_FP64" in v:  # the hardware's own flop counter, same normalisation (cross-check)
+                        v["fp64_flops_per_ray_step_hw_counter"] = (v["SQ_INSTS_VALU_FLOPS_FP64"] + v.get("SQ_INSTS_VALU_FLOPS_FP64_TRANS", 0.0)) * scale
     if sq:
         sq["_meta"] = meta(tag)
         for p in (os.path.join(dst, f"sq_counters_{tag}.json"), os.path.join(os.path.dirname(dst.rstrip("/")), "sq_counters_latest.json")):

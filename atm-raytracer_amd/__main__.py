@@ -54,7 +54,8 @@ def cmd_gen(a):
         stamp("Outputting metadata...")
         if meta_path.endswith(".npz"):  # this package's own array dump
             np.savez_compressed(meta_path, **{k: v for k, v in res.items() if isinstance(v, np.ndarray)})
-        else:  # the reference's format: gzip(bincode(AllData)), see metadata.py for the bytes that stay unpinned
+        else:  # gzip(bincode(AllData)) in the reference's field order — but with a stand-in `env` segment (metadata.py): this package's
+            # reader only; write_metadata warns on stderr every time
             from . import metadata
             metadata.write_metadata(meta_path, cfg, res, col, metadata.object_elevations(cfg, terrain))
     stamp("Done.")

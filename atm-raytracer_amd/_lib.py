@@ -36,6 +36,12 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def build_info():
+    """{'source_hash': ..., 'march_units': flags, 'calling_units': flags, 'all': flags, 'arch': ...} of the LOADED library."""
+    text = load().atmrt_build_info().decode()
+    return dict(part.split(": ", 1) for part in text.split("; ") if ": " in part)
+
+
 def build(force=False):
     """Compile libatmrt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
@@ -65,6 +71,7 @@ def load():
     sig = {
         "atmrt_abi_version": (C.c_int, []),
         "atmrt_abi_sizeof": (sz, [C.c_int]),
+        "atmrt_build_info": (C.c_char_p, []),
         "atmrt_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
         "atmrt_ctx_destroy": (None, [vp]),
         "atmrt_last_error": (C.c_char_p, [vp]),
@@ -114,7 +121,7 @@ def load():
     return L
 
 
-EXPORTED = ["atmrt_abi_version", "atmrt_ctx_create", "atmrt_ctx_destroy", "atmrt_last_error", "atmrt_terrain_load_dir",
+EXPORTED = ["atmrt_abi_version", "atmrt_build_info", "atmrt_ctx_create", "atmrt_ctx_destroy", "atmrt_last_error", "atmrt_terrain_load_dir",
             "atmrt_terrain_add_tile", "atmrt_terrain_clear", "atmrt_terrain_get_elev", "atmrt_params_default",
             "atmrt_atmosphere_us76", "atmrt_set_params", "atmrt_set_atmosphere", "atmrt_objects_set", "atmrt_generate",
             "atmrt_result_free", "atmrt_generate_device", "atmrt_last_hits_device", "atmrt_last_timings", "atmrt_last_stats", "atmrt_debug_fail_next_frame", "atmrt_coloring_from_conf", "atmrt_draw_image",

@@ -110,6 +110,14 @@ int read_dted(const char* path, int* lat0, int* lon0, HostTile* tile, std::strin
 // ---------------------------------------------------------------------------------------------
 extern "C" int atmrt_abi_version(void) { return ATMRT_ABI_VERSION; }
 
+#ifndef ATMRT_SOURCE_HASH
+#define ATMRT_SOURCE_HASH "unknown"
+#endif
+#ifndef ATMRT_BUILD_FLAGS
+#define ATMRT_BUILD_FLAGS "unknown"
+#endif
+extern "C" const char* atmrt_build_info(void) { return "source_hash: " ATMRT_SOURCE_HASH "; " ATMRT_BUILD_FLAGS; }
+
 extern "C" size_t atmrt_abi_sizeof(int which) {
   switch (which) {
     case 0: return sizeof(atmrt_params_t);

@@ -664,11 +664,11 @@ struct Earth {
   double shape_radius;
 };
 // bit 1 of Earth::flat_dirs: x / calc_radius may take dm_div — the radius and every stepper distance x lie within 1e-30 .. 1e30
-// (atmrt_set_params).  A bit of an existing field, not a new one: at 56 bytes the struct is passed to the out-of-line object code
-// (close_mask_impl, atmrt_march_impl.h) in registers; at 64 bytes hipcc 7.2 passes it through scratch, and with -disable-machine-licm
-// the general tracer then lost every object (golden case c5_rect_objects_opaque: 144 trace points instead of 574).
+// (atmrt_set_params).  A bit of an existing field rather than a new one keeps the struct at 56 bytes, which the out-of-line object
+// code (close_mask_impl, atmrt_march_impl.h) receives in registers.  Size is NOT a correctness matter: round 2 saw the tracer lose
+// its objects with a 64-byte Earth, but that was the IPRA failure of profiles/r03/ipra/README.md (a 64-byte Earth passes the object
+// tests once the calling units are built with -enable-ipra=0, checked in round 3).
 constexpr int32_t EARTH_FLAT_DIRS = 1, EARTH_FAST_DIV = 2;
-static_assert(sizeof(Earth) == 56, "Earth is passed by value to out-of-line device functions: keep it at 14 dwords");
 
 ATMRT_HD int earth_resolve(const atmrt_earth_model_t& m, Earth& e) {
   e.calc_radius = e.cart_radius = e.a = e.b = e.shape_radius = 0.0;

@@ -167,6 +167,11 @@ __global__ __launch_bounds__(256, DRAIN ? ATMRT_MARCH_WAVES_SMALL : ATMRT_MARCH_
           }
         }
         if (w_n > WAVE_CAND) object_ray = true; // the list overflowed: leave the whole wavefront to the tracer
+        // lane 0 wrote the list, every lane of the wavefront reads it from here on: DS operations of one wave issue in order, but the
+        // dependence has to exist for the compiler too — a wavefront-scope release / acquire pair around a wave barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int q = 0; q < w_n && q < WAVE_CAND; q++) // first interval that is not behind the start
           if (w_hi[wv][q] >= 0.0) x_wake = w_lo[wv][q] < x_wake ? w_lo[wv][q] : x_wake;
       }

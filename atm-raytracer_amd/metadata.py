@@ -281,7 +281,17 @@ def object_elevations(cfg, terrain):
 
 
 def write_metadata(path, cfg, res, coloring, object_elevs=(), vector3_len_prefix=True, env_encoder=encode_env, level=6):
-    """generator::output_metadata (src/generator/mod.rs:26-45): gzip(bincode(AllData { params, result }))."""
+    """generator::output_metadata (src/generator/mod.rs:26-45): gzip(bincode(AllData { params, result })).
+
+    NOT interchangeable with the reference as long as `env_encoder` is this module's stand-in: `Params.env` is
+    `atm_refraction::Environment`, whose serde layout lives in a crate that is absent here; bincode is not self-describing, so the
+    reference's `view` stops at that segment and cannot reach anything behind it, the whole `result` included.  Only
+    read_metadata() of this package reads such a file; a warning says so every time one is written."""
+    if env_encoder is encode_env:
+        import warnings
+        warnings.warn(f"{path}: the `env` segment is this package's stand-in (crate atm-refraction absent): the file is readable by "
+                      "atm_raytracer_amd.metadata.read_metadata only, NOT by the reference's `atm-raytracer view`; pass env_encoder= "
+                      "with the crate's bincode layout to write an interchangeable file", stacklevel=2)
     z = zlib.compressobj(level, zlib.DEFLATED, 31)  # wbits 31: gzip container, what libflate::gzip::Encoder writes
     with open(path, "wb") as f:
         f.write(z.compress(encode_params(cfg, list(object_elevs), coloring, vector3_len_prefix, env_encoder)))

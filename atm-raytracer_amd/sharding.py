@@ -1,8 +1,13 @@
 """Pixel-column tile sharding across the GPUs of one node: rank g of G owns columns
 [g*W/G, (g+1)*W/G); rows and the terrain mosaic are replicated (pixels are independent, rectilinear.rs:32-37).
 
+SINCE ROUND 3 THE PRODUCT PATH IS C++: csrc/atmrt_multi.hip does all of this below the C ABI (atmrt_ctx_create_multi,
+atmrt_ctx_comm_init_rank, atmrt_generate_image_device, atmrt_image_hits_device — hand-written against RCCL), and bench.py uses
+that.  This module stays as the torch.distributed statement of the same exchange for hosts that drive their ranks from Python
+and as the CPU-testable model of the layout (tests/test_distributed_cpu.py: world_size 2 over gloo).
+
 The only exchange is at the end of the frame and it is ONE collective: every rank's result planes live in one contiguous
-slab (`PlaneSlab`: 7 f64 planes + the planar normal + hit_count, 88 B per pixel), `gather_image` all-gathers the slabs with a
+slab (`PlaneSlab`: 7 f64 planes + the planar normal + hit_count, 84 B per pixel), `ImageGather` all-gathers the slabs with a
 single all_gather_into_tensor and permutes the rank-major slabs into the [H][W] row-major image `result[y][x]` (fast.rs:52-92)
 — the permutation is part of the step, so what a caller times is the time to the finished image.  Frames whose pixels hold
 several trace points (translucent terrain, scene objects — BASELINE config 5) additionally exchange the variable-length lists:

@@ -236,14 +236,17 @@ def main():
         out = {}
         if world != 1 or (W, H) != (4096, 2048) or args.scene != "headline" or args.objects or args.terrain_alpha != 1.0:
             return out
+        if os.environ.get("ATMRT_LIB"):  # an experimental build: nothing cached was collected from it
+            return {"sq_stale": "ATMRT_LIB is set: cached counters are never quoted for a development build"}
+        built_from = _lib.build_info()["source_hash"]  # of the library that is LOADED, embedded at build time
         for key, name in (("hbm", "pmc_hbm_latest.json"), ("sq", "sq_counters_latest.json")):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
             doc = json.load(open(path))
             meta = doc.get("_meta", {})
-            if meta.get("source_hash") != _lib.source_hash():
-                out[key + "_stale"] = f"profiles/{name} was collected from sources {meta.get('source_hash')}, this tree is {_lib.source_hash()}"
+            if meta.get("source_hash") != built_from:
+                out[key + "_stale"] = f"profiles/{name} was collected from sources {meta.get('source_hash')}, the loaded library was built from {built_from}"
                 continue
             for k, v in doc.items():
                 if kernel in k:
@@ -255,9 +258,11 @@ def main():
         HBM side: ALGORITHMIC bytes: 8 B per terrain sample actually evaluated (the 4 int16 posts of one bilinear
         lookup; the march skips the samples of rays above every post) + what the kernel stores per pixel; the Fast
         scan is credited 8 B per ray-step, the path kernel 16 B per step of every row, the terrain profile 16 B per sample.
-        Compute side (k_rect_march is FP64-VALU bound, not HBM bound): VALU lane-instructions per second against the FP64 issue
-        peak (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz; x2 = the 78.6 TFLOP/s vector peak counted in FMAs), with the
-        instructions per ray-step from the committed SQ-counter passes of this same command when they match this build."""
+        Compute side (k_rect_march is FP64-VALU bound, not HBM bound): `achieved` is a real FLOP rate — FP64 flops per ray-step from
+        the SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 counters of the committed rocprofv3 passes of this same command (FMA = 2 flops, add /
+        mul / transcendental = 1; quoted only when collected from this build) x the ray-steps per second measured live — against
+        the 78.6 TFLOP/s FP64 vector peak.  `issue_slot_frac` is the other view: ALL VALU lane-instructions per second (moves,
+        compares, integer index arithmetic included) against the issue peak of 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz."""
         mean = lambda k: float(np.mean([p[k] for p in phase]))
         steps_per_launch = mean("ray_steps")
         lookups = mean("terrain_lookups")
@@ -285,16 +290,25 @@ def main():
         sq = cached.get("sq")
         ipr = sq.get("valu_lane_instructions_per_ray_step") if sq else None
         if kernel == "k_rect_march" and ipr:
-            rate = ipr * steps_per_launch / (ms * 1e-3)
-            out = {"bound": "fp64_valu", "achieved": 2.0 * rate / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                   "frac": rate / FP64_ISSUE_PEAK, "traffic": traffic,
-                   "note": "FP64-issue bound: every VALU lane-instruction counted as one FMA slot (2 flop) against the 78.6 TFLOP/s vector "
-                           "peak; achieved = instructions per ray-step (cached SQ counters of this build) x live ray-steps/s",
-                   "valu": {"cached": True, "file": sq["file"], "source_hash": sq["source_hash"], "collected": sq.get("collected"),
-                            "valu_lane_instructions_per_ray_step": ipr, "busy_frac": sq.get("valu_busy_frac"),
-                            "lane_utilisation": sq.get("lane_utilisation"), "lane_instructions_per_s": rate,
-                            "fp64_issue_peak_per_s": FP64_ISSUE_PEAK},
-                   "hbm": hbm}
+            steps_per_s = steps_per_launch / (ms * 1e-3)
+            rate = ipr * steps_per_s
+            flops = sq.get("fp64_flops_per_ray_step")
+            valu = {"cached": True, "file": sq["file"], "source_hash": sq["source_hash"], "collected": sq.get("collected"),
+                    "valu_lane_instructions_per_ray_step": ipr, "busy_frac": sq.get("valu_busy_frac"),
+                    "lane_utilisation": sq.get("lane_utilisation"), "lane_instructions_per_s": rate,
+                    "fp64_issue_peak_per_s": FP64_ISSUE_PEAK, "fp64_flops_per_ray_step": flops,
+                    "fp64_flops_per_ray_step_hw_counter": sq.get("fp64_flops_per_ray_step_hw_counter"),
+                    "lane_instructions_per_ray_step_by_kind": sq.get("lane_instructions_per_ray_step_by_kind")}
+            if flops:
+                out = {"bound": "fp64_valu", "achieved": flops * steps_per_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": flops * steps_per_s / 1e12 / FP64_VALU_PEAK_TF, "issue_slot_frac": rate / FP64_ISSUE_PEAK, "traffic": traffic,
+                       "note": "achieved = FP64 flops per ray-step (SQ_INSTS_VALU_ADD/MUL/FMA/TRANS_F64 of this build's cached rocprofv3 passes; "
+                               "FMA = 2) x live ray-steps/s; issue_slot_frac = all VALU lane-instructions/s over the FP64 issue peak: the "
+                               "pipes are that full, of which 72 % FP64 arithmetic — the rest is table-index integer work, compares, moves",
+                       "valu": valu, "hbm": hbm}
+            else:  # counters from before the instruction-mix passes existed: issue slots only, labelled as such
+                out = {"bound": "fp64_valu_issue", "achieved": rate / 1e12, "peak": FP64_ISSUE_PEAK / 1e12, "unit": "T lane-instructions/s",
+                       "frac": rate / FP64_ISSUE_PEAK, "issue_slot_frac": rate / FP64_ISSUE_PEAK, "traffic": traffic, "valu": valu, "hbm": hbm}
         elif "sq_stale" in cached:
             out["valu"] = {"stale": cached["sq_stale"]}
         out.update({"kernel": kernel, "kernel_ms": ms, "terrain_samples_per_launch": lookups if kernel == "k_rect_march" else None,

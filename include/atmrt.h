@@ -194,6 +194,9 @@ typedef struct atmrt_ctx atmrt_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int atmrt_abi_version(void);
+/* "source_hash: <sha256/16 of csrc + Makefile + this header>; march_units: <flags>; calling_units: <flags>; all: <flags>; arch: gfx950":
+ * what the library was built from and with which code-generation flags (the calling units must carry -enable-ipra=0). */
+const char* atmrt_build_info(void);
 /* device_ordinal: HIP device index (LOCAL_RANK under torchrun).  Fails with ATMRT_ERR_NO_DEVICE
  * when no GPU is present — there is no CPU path in this library. */
 int atmrt_ctx_create(atmrt_ctx** out, int device_ordinal);

@@ -47,6 +47,15 @@ def test_defaults_match_the_reference(lib):
     assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 4
 
 
+def test_build_info_names_the_sources_and_the_required_flags(lib):
+    """The library says what it was built from: the hash equals the tree's (a stale .so would be caught here), and the units whose
+    kernels call device functions were compiled without interprocedural register allocation (profiles/r03/ipra/README.md)."""
+    info = _lib.build_info()
+    assert info["source_hash"] == _lib.source_hash(), "libatmrt.so was not built from this tree: run make -C atm-raytracer_amd/csrc"
+    assert "-enable-ipra=0" in info["calling_units"] and "-disable-machine-licm" in info["march_units"] and info["arch"] == "gfx950"
+    assert "-ffp-contract=off" in info["all"]
+
+
 def test_no_cpu_fallback(lib):
     import torch
     if torch.cuda.device_count() > 0:

@@ -143,7 +143,7 @@ class CommTimings(C.Structure):
                 ("bytes_per_rank", C.c_uint64), ("world", C.c_int32), ("route", C.c_int32), ("collectives", C.c_int32), ("_pad", C.c_int32)]
 
 
-ROUTES = {0: "none", 1: "rccl", 2: "peer", 3: "external", 4: "host"}
+ROUTES = {0: "none", 1: "rccl", 2: "peer", 3: "external", 4: "host", 5: "external-device"}
 COMM_ID_BYTES = 128
 # atmrt_all_gather_fn(user, send_host, recv_host, bytes_per_rank) -> int
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)

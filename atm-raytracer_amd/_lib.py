@@ -104,6 +104,7 @@ def load():
         "atmrt_comm_unique_id": (C.c_int, [vp]),
         "atmrt_ctx_comm_init_rank": (C.c_int, [vp, vp, i32, i32]),
         "atmrt_ctx_comm_init_external": (C.c_int, [vp, i32, i32, _abi.ALL_GATHER_FN, vp]),
+        "atmrt_ctx_comm_init_external_device": (C.c_int, [vp, i32, i32, _abi.ALL_GATHER_FN, vp]),
         "atmrt_ctx_create_multi": (C.c_int, [C.POINTER(vp), C.POINTER(i32), i32]),
         "atmrt_ctx_device_count": (C.c_int, [vp]),
         "atmrt_generate_image_device": (C.c_int, [vp, C.POINTER(_abi.DevicePlanes), C.POINTER(C.c_uint64), pd]),
@@ -127,6 +128,6 @@ EXPORTED = ["atmrt_abi_version", "atmrt_build_info", "atmrt_ctx_create", "atmrt_
             "atmrt_result_free", "atmrt_generate_device", "atmrt_last_hits_device", "atmrt_last_timings", "atmrt_last_stats", "atmrt_debug_fail_next_frame", "atmrt_coloring_from_conf", "atmrt_draw_image",
             "atmrt_draw_image_device", "atmrt_ray_paths", "atmrt_atmosphere_sample",
             "atmrt_coords_at_dist", "atmrt_math_probe", "atmrt_result_encode_bincode",
-            "atmrt_result_decode_bincode", "atmrt_comm_unique_id", "atmrt_ctx_comm_init_rank", "atmrt_ctx_comm_init_external",
+            "atmrt_result_decode_bincode", "atmrt_comm_unique_id", "atmrt_ctx_comm_init_rank", "atmrt_ctx_comm_init_external", "atmrt_ctx_comm_init_external_device",
             "atmrt_ctx_create_multi", "atmrt_ctx_device_count", "atmrt_generate_image_device", "atmrt_image_hits_device",
             "atmrt_draw_image_gathered_device", "atmrt_last_comm_timings"]

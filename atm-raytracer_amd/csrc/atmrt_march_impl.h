@@ -66,6 +66,9 @@ constexpr int WAVE_CAND = 96;                // entries of a wavefront's list; m
 constexpr int DRAIN_PRIO_BAND = 512;
 // Test hook: ATMRT_MARCH_VARIANT=plain / small forces one variant for every launch, so that the random sweeps (small frames) can be
 // run over the kernel the full-size frames use, and the other way round.  Same results either way.
+#ifndef ATMRT_MARCH_BLOCK_SMALL
+#define ATMRT_MARCH_BLOCK_SMALL 256 // workgroup size of the small-launch (DRAIN) variant
+#endif
 static inline int march_variant_override() {
   static const int v = [] {
     const char* e = getenv("ATMRT_MARCH_VARIANT");
@@ -79,7 +82,8 @@ static inline int march_variant_override() {
     const unsigned blocks_ = cdiv((size_t)(N), 256);                                                                                   \
     const int override_ = march_variant_override();                                                                                    \
     if (override_ ? override_ == 2 : blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                               \
-      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, true>), dim3(blocks_), dim3(256), 0, STREAM, \
+      ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, true>),                                    \
+                                                            dim3(cdiv((size_t)(N), ATMRT_MARCH_BLOCK_SMALL)), dim3(ATMRT_MARCH_BLOCK_SMALL), 0, STREAM, \
                                                             __VA_ARGS__));                                                             \
     } else {                                                                                                                           \
       ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, false>), dim3(blocks_), dim3(256), 0, STREAM, \
@@ -96,7 +100,7 @@ static inline int march_variant_override() {
 #define ATMRT_MARCH_WAVES_SMALL 5
 #endif
 template <int MODE, int CALC, bool CUBIC, bool DRAIN>
-__global__ __launch_bounds__(256, DRAIN ? ATMRT_MARCH_WAVES_SMALL : ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+__global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMRT_MARCH_WAVES_SMALL : ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,

@@ -124,6 +124,7 @@ struct Comm {
   ncclComm_t nccl = nullptr;
   MultiGroup* group = nullptr; // the devices of one process (peer copies, host threads)
   atmrt_all_gather_fn ext = nullptr;
+  atmrt_all_gather_device_fn ext_dev = nullptr;
   void* ext_user = nullptr;
   hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr, ev_a1 = nullptr;
   DevBuf d_slab, d_gathered, d_small, d_hits_send, d_hits_recv, d_loc_off, d_scan_tmp, d_rgb_tile, d_rgb_all;
@@ -340,7 +341,7 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 int comm_all_gather(atmrt_ctx* c, const void* send, void* recv, size_t bytes) {
   Comm* cm = c->comm;
   hipStream_t s = c->stream;
-  if (!cm || cm->world == 1) {
+  if (!cm || (cm->world == 1 && cm->route != ATMRT_ROUTE_EXTERNAL && cm->route != ATMRT_ROUTE_EXTERNAL_DEVICE)) {
     if (cm && cm->nccl) { // RCCL at world size 1: the same call as with 8 ranks
       NCCL_TRY(c, rccl()->AllGather(send, recv, bytes, ncclUint8, cm->nccl, s));
       return ATMRT_OK;
@@ -374,6 +375,12 @@ int comm_all_gather(atmrt_ctx* c, const void* send, void* recv, size_t bytes) {
       const int rc = cm->ext(cm->ext_user, cm->h_send.ptr, cm->h_recv.ptr, bytes);
       if (rc) return c->fail(ATMRT_ERR_HIP, "the host's all-gather callback returned %d", rc);
       HIP_TRY(c, hipMemcpyAsync(recv, cm->h_recv.ptr, bytes * (size_t)cm->world, hipMemcpyHostToDevice, s));
+      return ATMRT_OK;
+    }
+    case ATMRT_ROUTE_EXTERNAL_DEVICE: {
+      HIP_TRY(c, hipStreamSynchronize(s));
+      const int rc = cm->ext_dev(cm->ext_user, send, recv, bytes);
+      if (rc) return c->fail(ATMRT_ERR_HIP, "the host's device all-gather callback returned %d", rc);
       return ATMRT_OK;
     }
     default:
@@ -650,6 +657,16 @@ extern "C" int atmrt_ctx_comm_init_external(atmrt_ctx* c, int32_t rank, int32_t 
   c->comm->ext = fn;
   c->comm->ext_user = user;
   c->comm->route = ATMRT_ROUTE_EXTERNAL;
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_ctx_comm_init_external_device(atmrt_ctx* c, int32_t rank, int32_t world, atmrt_all_gather_device_fn fn, void* user) {
+  if (!c || !fn) return ATMRT_ERR_INVALID_ARGUMENT;
+  int rc = comm_attach(c, rank, world);
+  if (rc) return rc;
+  c->comm->ext_dev = fn;
+  c->comm->ext_user = user;
+  c->comm->route = ATMRT_ROUTE_EXTERNAL_DEVICE;
   return ATMRT_OK;
 }
 

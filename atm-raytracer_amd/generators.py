@@ -76,6 +76,21 @@ class Context:
         self._transport = _abi.ALL_GATHER_FN(thunk)  # keep the trampoline alive as long as the context
         self.check(self.lib.atmrt_ctx_comm_init_external(self.handle, rank, world, self._transport, None))
 
+    def comm_init_external_device(self, rank, world, all_gather):
+        """all_gather(send_ptr, recv_ptr, nbytes) moves DEVICE memory (e.g. through the torch.distributed communicator the host
+        already owns: torch_device_all_gather below) and returns when the gathered bytes are in place."""
+        def thunk(_user, send, recv, nbytes):
+            try:
+                all_gather(send, recv, nbytes)
+                return 0
+            except Exception as exc:
+                import traceback
+                traceback.print_exc()
+                self._transport_error = exc
+                return 1
+        self._transport = _abi.ALL_GATHER_FN(thunk)
+        self.check(self.lib.atmrt_ctx_comm_init_external_device(self.handle, rank, world, self._transport, None))
+
     def comm_timings(self):
         t = _abi.CommTimings()
         self.check(self.lib.atmrt_last_comm_timings(self.handle, C.byref(t)))
@@ -97,6 +112,26 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class _DeviceBytes:
+    """A raw device pointer as a __cuda_array_interface__ object, so that torch can wrap it without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def torch_device_all_gather(dist, device):
+    """An all_gather for Context.comm_init_external_device over torch.distributed's own communicator (RCCL on device tensors)."""
+    import torch
+
+    def all_gather(send, recv, nbytes):
+        world = dist.get_world_size()
+        s = torch.as_tensor(_DeviceBytes(send, nbytes), device=device)
+        r = torch.as_tensor(_DeviceBytes(recv, nbytes * world), device=device)
+        dist.all_gather_into_tensor(r, s)
+        torch.cuda.synchronize(device)
+    return all_gather
 
 
 class Terrain:

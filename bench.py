@@ -161,12 +161,31 @@ def main():
             def all_gather(send, recv):
                 dist.all_gather_into_tensor(torch.frombuffer(recv, dtype=torch.uint8), torch.frombuffer(send, dtype=torch.uint8))
             ctx.comm_init_external(rank, world, all_gather)
+        elif os.environ.get("ATMRT_BENCH_TRANSPORT") == "torch":
+            # the library's exchange and assembly, but the bytes moved by torch.distributed's communicator (device tensors)
+            ctx.comm_init_external_device(rank, world, generators.torch_device_all_gather(dist, dev))
         else:
             ident = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                ident.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                if rank == 0:
+                    ident.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            except Exception as exc:  # RCCL not loadable from the library: every rank must take the same road
+                log(f"[rank {rank}] atmrt_comm_unique_id failed ({exc}); falling back to torch.distributed's communicator")
+                ok.zero_()
+            dist.broadcast(ok, 0)
             dist.broadcast(ident, 0)
-            ctx.comm_init_rank(bytes(ident.cpu().numpy()), rank, world)
+            if int(ok.item()):
+                try:
+                    ctx.comm_init_rank(bytes(ident.cpu().numpy()), rank, world)
+                except Exception as exc:
+                    log(f"[rank {rank}] atmrt_ctx_comm_init_rank failed ({exc})")
+                    ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # one rank without its communicator: nobody uses it
+            if not int(ok.item()):
+                ctx.close()  # a context holds at most one communicator: start over
+                ctx = generators.Context(local_rank)
+                ctx.comm_init_external_device(rank, world, generators.torch_device_all_gather(dist, dev))
     terrain = generators.Terrain.from_tiles(tiles, ctx)
     log(f"[rank {rank}] scene ready in {time.perf_counter() - t_setup:.1f} s: {W}x{H}, columns [{c0},{c1}), "
         f"{len(tiles)} tiles of {next(iter(tiles.values())).shape}")

@@ -348,6 +348,11 @@ int atmrt_ctx_comm_init_rank(atmrt_ctx* ctx, const uint8_t id[ATMRT_COMM_ID_BYTE
  * tiles back into HBM around the call. */
 typedef int (*atmrt_all_gather_fn)(void* user, const void* send_host, void* recv_host, size_t bytes_per_rank);
 int atmrt_ctx_comm_init_external(atmrt_ctx* ctx, int32_t rank, int32_t world, atmrt_all_gather_fn all_gather, void* user);
+/* The same for a transport that moves DEVICE memory itself (a GPU-aware MPI, another RCCL communicator the host already owns):
+ * both pointers are in this context's HBM; the library's stream has drained when the callback is entered and the gathered bytes
+ * must be in place when it returns. */
+typedef int (*atmrt_all_gather_device_fn)(void* user, const void* send_device, void* recv_device, size_t bytes_per_rank);
+int atmrt_ctx_comm_init_external_device(atmrt_ctx* ctx, int32_t rank, int32_t world, atmrt_all_gather_device_fn all_gather, void* user);
 /* One context over n_devices HIP devices of this process (1): terrain, parameters, atmosphere and objects set on it reach every
  * device.  A device may be listed more than once (its tiles then are exchanged by device-to-device copies; RCCL needs distinct
  * devices).  ATMRT_GATHER=peer forces that route, ATMRT_GATHER=rccl makes a failure to set RCCL up an error instead of a fallback. */
@@ -372,7 +377,8 @@ typedef enum atmrt_gather_route {
   ATMRT_ROUTE_RCCL = 1,     /* ncclAllGather over xGMI */
   ATMRT_ROUTE_PEER = 2,     /* device-to-device copies inside one process */
   ATMRT_ROUTE_EXTERNAL = 3, /* the host's transport (atmrt_ctx_comm_init_external) */
-  ATMRT_ROUTE_HOST = 4      /* atmrt_generate on a multi-device context: strided copies into the host block */
+  ATMRT_ROUTE_HOST = 4,     /* atmrt_generate on a multi-device context: strided copies into the host block */
+  ATMRT_ROUTE_EXTERNAL_DEVICE = 5 /* the host's device-memory transport (atmrt_ctx_comm_init_external_device) */
 } atmrt_gather_route;
 typedef struct atmrt_comm_timings {
   double gather_ms;         /* the collective (or the copies) */

@@ -1,6 +1,8 @@
 // gen_host.cpp — the reference's `generator::generate` flow (src/generator/mod.rs:47-99, minus renderer and metadata)
 // written against the C++ host mirror: Terrain::from_folder -> Params -> make_generator -> generate().
-// Usage: gen_host TERRAIN_DIR GENERATOR(Fast|Rectilinear|InterpolatingRectilinear) WIDTH HEIGHT OUT.bin
+// Usage: gen_host TERRAIN_DIR GENERATOR(Fast|Rectilinear|InterpolatingRectilinear) WIDTH HEIGHT OUT.bin [DEVICES]
+// DEVICES: comma-separated HIP device ordinals, e.g. 0,1,2,3,4,5,6,7 — the frame is then cut into pixel-column tiles inside the
+// library (a device may be listed twice: "0,0" is two tiles on one GPU); the host code below is the same either way.
 // Writes per pixel: azimuth, elevation_angle, n_trace_points, then the first trace point (lat lon distance elevation) or
 // four NaNs, as float64 — tests/test_host_cpp.py compares the file with the oracle.
 #include <cmath>
@@ -13,12 +15,19 @@
 using namespace atmrt_host;
 
 int main(int argc, char** argv) {
-  if (argc != 6) {
-    fprintf(stderr, "usage: %s TERRAIN_DIR GENERATOR WIDTH HEIGHT OUT.bin\n", argv[0]);
+  if (argc != 6 && argc != 7) {
+    fprintf(stderr, "usage: %s TERRAIN_DIR GENERATOR WIDTH HEIGHT OUT.bin [DEVICES]\n", argv[0]);
     return 2;
   }
   try {
-    Terrain terrain = Terrain::from_folder(argv[1]);
+    std::vector<int> devices;
+    if (argc == 7)
+      for (const char* p = argv[6]; *p;) {
+        devices.push_back((int)strtol(p, const_cast<char**>(&p), 10));
+        if (*p == ',') p++;
+      }
+    Terrain terrain = devices.empty() ? Terrain::from_folder(argv[1]) : Terrain::from_folder(argv[1], devices);
+    if (!devices.empty()) printf("%d devices\n", terrain.devices());
     printf("Detected %d terrain files\n", terrain.files()); // terrain/mod.rs:80
     Params params;
     params.position = Position{46.5, 8.5, Altitude{Altitude::Relative, 50.0}};

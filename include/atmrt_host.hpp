@@ -13,6 +13,9 @@
 //   ResultPixel / TracePoint / PixelColor  generators/mod.rs:13-80   same names
 //   panic!/expect on bad input                                       throws std::runtime_error with the library's message
 //
+//   (one GPU in the reference's world)                               Terrain(std::vector<int> devices): the same frame cut into
+//                                                                    pixel-column tiles over several GPUs, inside the library
+//
 // Link with -latmrt.  There is no CPU path: constructing a Terrain without a gfx950 device throws.
 #pragma once
 
@@ -87,8 +90,9 @@ struct Params { // params.rs:496-505 (the fields that reach the generators); def
   GeneratorDef generator = GeneratorDef::Fast;
   double terrain_alpha = 1.0;
   std::vector<Object> objects;
-  std::optional<atmrt_atmosphere_t> atmosphere; // None = AtmosphereDef::us_76()
-  uint16_t col_begin = 0, col_end = 0;          // pixel-column shard, 0/0 = whole image
+  std::optional<atmrt_atmosphere_t> atmosphere; // None = AtmosphereDef::us_76(); the function table and spline points it points at
+                                                // are the caller's and must outlive generate() (any number of either)
+  uint16_t col_begin = 0, col_end = 0;          // pixel-column shard, 0/0 = whole image (leave 0/0 on a multi-device Terrain)
 
   atmrt_params_t pod(GeneratorDef gen) const {
     atmrt_params_t p{};
@@ -108,7 +112,9 @@ struct Params { // params.rs:496-505 (the fields that reach the generators); def
   }
 };
 
-// Terrain, terrain/mod.rs:55-57.  Owns the device context the tiles live in.
+// Terrain, terrain/mod.rs:55-57.  Owns the device context the tiles live in — one GPU, or several: with a device list the
+// library cuts every frame into pixel-column tiles (one per device, one host thread each, the mosaic in every device's HBM) and
+// generate() still returns the whole Vec<Vec<ResultPixel>>; nothing else in the host code changes.
 class Terrain {
  public:
   explicit Terrain(int device = 0) {
@@ -117,13 +123,16 @@ class Terrain {
     if (rc) throw Error(rc, atmrt_last_error(nullptr));
     ctx_.reset(c, atmrt_ctx_destroy);
   }
-  static Terrain from_folder(const std::string& terrain_folder, int device = 0) {
-    Terrain t(device);
-    int32_t n = 0;
-    t.check(atmrt_terrain_load_dir(t.ctx(), terrain_folder.c_str(), &n));
-    t.files_ = n;
-    return t;
+  explicit Terrain(const std::vector<int>& devices) {
+    atmrt_ctx* c = nullptr;
+    std::vector<int32_t> d(devices.begin(), devices.end());
+    int rc = atmrt_ctx_create_multi(&c, d.data(), (int32_t)d.size());
+    if (rc) throw Error(rc, atmrt_last_error(nullptr));
+    ctx_.reset(c, atmrt_ctx_destroy);
   }
+  static Terrain from_folder(const std::string& terrain_folder, int device = 0) { return Terrain(device).load(terrain_folder); }
+  static Terrain from_folder(const std::string& terrain_folder, const std::vector<int>& devices) { return Terrain(devices).load(terrain_folder); }
+  int devices() const { return atmrt_ctx_device_count(ctx()); }
   void add_tile(int lat0, int lon0, int n_lat, int n_lon, const int16_t* posts) { check(atmrt_terrain_add_tile(ctx(), lat0, lon0, n_lat, n_lon, posts)); }
   std::optional<double> get_elev(double latitude, double longitude) const {
     double e = 0.0;
@@ -133,6 +142,12 @@ class Terrain {
   }
   int files() const { return files_; }
   atmrt_ctx* ctx() const { return ctx_.get(); }
+  Terrain& load(const std::string& terrain_folder) {
+    int32_t n = 0;
+    check(atmrt_terrain_load_dir(ctx(), terrain_folder.c_str(), &n));
+    files_ = n;
+    return *this;
+  }
   void check(int rc) const { if (rc) throw Error(rc, atmrt_last_error(ctx())); }
  private:
   std::shared_ptr<atmrt_ctx> ctx_;

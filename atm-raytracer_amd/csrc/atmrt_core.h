@@ -370,7 +370,13 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
     tmin = t0 < t1 ? t0 : t1;
     tmax = t0 < t1 ? t1 : t0;
     if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
-    const double p0 = pb * atm_pressure_ratio(t, k, lo), p1 = pb * atm_pressure_ratio(t, k, hi);
+    // p / pb = exp(e) with e = expo * log(T / tb) (or expo * (h - hb) on an isothermal segment): monotone in h, so the end points
+    // bound it.  Within 1e-280 .. 1e280 means |e| <= 645 < 700 at every point of the interval: the certified evaluation may call
+    // the main branch of exp without asking (refr_n_layer3) — and T / tb, a ratio of two temperatures in 1 .. 1e5 K, is a positive
+    // normal number: the main branch of log likewise.
+    const double r0 = atm_pressure_ratio(t, k, lo), r1 = atm_pressure_ratio(t, k, hi);
+    if (!(r0 >= 1.0e-280 && r0 <= 1.0e280 && r1 >= 1.0e-280 && r1 <= 1.0e280)) return false;
+    const double p0 = pb * r0, p1 = pb * r1;
     pmin = p0 < p1 ? p0 : p1;
     pmax = p0 < p1 ? p1 : p0;
   }
@@ -549,6 +555,16 @@ ATMRT_HD void exp3(double e0, double e1, double e2, double& r0, double& r1, doub
   r1 = dm_exp(e1);
   r2 = dm_exp(e2);
 }
+// the same for arguments the certificate has already placed in the main ranges of log and exp (atm_interval_certified): no votes
+ATMRT_HD void pow3_in_range(double x0, double x1, double x2, double y, double& r0, double& r1, double& r2) {
+  const double e0 = y * dm_log_core_pow(x0), e1 = y * dm_log_core_pow(x1), e2 = y * dm_log_core_pow(x2);
+  r0 = dm_exp_main(e0);
+  r1 = dm_exp_main(e1);
+  r2 = dm_exp_main(e2);
+}
+// Only for points inside a certified interval [safe_lo, safe_hi) of a segment (the callers' wave votes): there T / tb is a positive
+// normal number and |expo log(T / tb)| (|expo (h - hb)| on an isothermal segment) is at most 645, so log and exp take their main
+// branches unasked — the values of refr_n_layer at the three points.
 template <bool CUBIC = true>
 ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, double rtb, double pb, double lapse, double c2, double c3,
                             double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2) {
@@ -560,8 +576,13 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, doub
   }
   const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
   double r0, r1, r2;
-  if (lapse != 0.0) pow3(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
-  else exp3(expo * (h0 - hb), expo * (h1 - hb), expo * (h2 - hb), r0, r1, r2);
+  if (lapse != 0.0) {
+    pow3_in_range(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
+  } else {
+    r0 = dm_exp_main(expo * (h0 - hb));
+    r1 = dm_exp_main(expo * (h1 - hb));
+    r2 = dm_exp_main(expo * (h2 - hb));
+  }
   refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
 }
 

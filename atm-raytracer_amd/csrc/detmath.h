@@ -380,11 +380,18 @@ DM_FN double dm_asin(double x) {
 
 /* Where the tables of exp and log are read from: the constant arrays of detmath_tables.h, or — in a GPU translation unit that
  * defines DM_TABLES_LDS as a __shared__ double[768] which each of its kernels fills first (log rows, then exp rows) — from LDS. */
+/* u = ((hi + 0x1000) & ~0x1fff) - 0x3fe6a000: the constant's low 13 bits are zero, so it commutes with the mask — one addition
+ * instead of two (integer identity modulo 2^32: the same u on every platform).  The row of u is table entry (u >> 13) & 127; the
+ * LDS form addresses it by its byte offset (u >> 8) & 0xfe0 directly (rows are 32 bytes): two integer instructions, not three. */
+#define DM_LOG_CENTRE(hi) ((int32_t)(((hi) + (0x1000u - 0x3fe6a000u)) & 0xffffe000u))
+#define DM_LOG_Z_HI(hi, u, k) ((hi) - ((uint32_t)(u) & 0xfff00000u)) /* high word of z = x 2^-k */
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DM_TABLES_LDS)
 #define DM_LOG_ROW(i) (&DM_TABLES_LDS[4 * (i)])
+#define DM_LOG_ROW_OF(u) ((const double*)((const char*)DM_TABLES_LDS + (((uint32_t)(u) >> 8) & 0xfe0u)))
 #define DM_EXP_ROW(j) (&DM_TABLES_LDS[512 + 2 * (j)])
 #else
 #define DM_LOG_ROW(i) DM_LOG_TAB[i]
+#define DM_LOG_ROW_OF(u) DM_LOG_TAB[((u) >> 13) & 127]
 #define DM_EXP_ROW(j) DM_EXP_TAB[j]
 #endif
 
@@ -453,10 +460,10 @@ DM_FN double dm_exp(double x) {
 DM_FN double dm_log_core(double x, int32_t k0) {
   uint64_t ix = dm_bits(x);
   uint32_t hi = (uint32_t)(ix >> 32);
-  int32_t u = (int32_t)(((hi + 0x1000u) & 0xffffe000u) - 0x3fe6a000u); /* nearest centre, relative to 0.70703125 */
+  int32_t u = DM_LOG_CENTRE(hi); /* nearest centre, relative to 0.70703125 */
   int32_t k = u >> 20;
-  const double* t = DM_LOG_ROW((u >> 13) & 127);
-  double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)(hi - ((uint32_t)u & 0xfff00000u)) << 32));
+  const double* t = DM_LOG_ROW_OF(u);
+  double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)DM_LOG_Z_HI(hi, u, k) << 32));
   double r = DM_FMA(z, t[0], -1.0);
   double kd = (double)(k + k0);
   double w = DM_FMA(kd, DM_LN2_HI, t[1]);
@@ -478,10 +485,10 @@ DM_FN double dm_log_core(double x, int32_t k0) {
 DM_FN double dm_log_core_pow(double x) {
   uint64_t ix = dm_bits(x);
   uint32_t hi = (uint32_t)(ix >> 32);
-  int32_t u = (int32_t)(((hi + 0x1000u) & 0xffffe000u) - 0x3fe6a000u);
+  int32_t u = DM_LOG_CENTRE(hi);
   int32_t k = u >> 20;
-  const double* t = DM_LOG_ROW((u >> 13) & 127);
-  double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)(hi - ((uint32_t)u & 0xfff00000u)) << 32));
+  const double* t = DM_LOG_ROW_OF(u);
+  double z = dm_from_bits((ix & 0xffffffffULL) | ((uint64_t)DM_LOG_Z_HI(hi, u, k) << 32));
   double r = DM_FMA(z, t[0], -1.0);
   double kd = (double)k;
   double w = DM_FMA(kd, DM_LN2_HI, t[1]);

@@ -33,7 +33,8 @@ int ch_cart(const atmrt_earth_model_t* m, double lat, double lon, double elev, d
 // atm_certify: the altitude interval of every segment inside which the GPU may take its shortcut divisions, and an independent check
 // of the certificate: min T, max p/T, max |Z - 1| and max n over a dense sample of the interval
 int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, double radius, double step, int* n_seg, double* from,
-               double* safe_lo, double* safe_hi, double* band2, double* min_t, double* max_pt, double* max_z_dev, double* max_n) {
+               double* safe_lo, double* safe_hi, double* band2, double* min_t, double* max_pt, double* max_z_dev, double* max_n,
+               double* max_abs_e) {
   AtmTableBuf buf;
   if (atm_compile(*def, wavelength, buf)) return -1;
   AtmTable& a = buf.table();
@@ -45,7 +46,7 @@ int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, 
     from[k] = a.seg(k).from;
     safe_lo[k] = a.seg(k).safe_lo;
     safe_hi[k] = a.seg(k).safe_hi;
-    min_t[k] = 1e300; max_pt[k] = max_z_dev[k] = max_n[k] = 0.0;
+    min_t[k] = 1e300; max_pt[k] = max_z_dev[k] = max_n[k] = max_abs_e[k] = 0.0;
     if (!(a.seg(k).safe_lo < a.seg(k).safe_hi)) continue;
     const int N = 4000;
     for (int i = 0; i <= N; i++) {
@@ -58,6 +59,11 @@ int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, 
       double zd = z > 1.0 ? z - 1.0 : 1.0 - z;
       if (!(zd <= max_z_dev[k])) max_z_dev[k] = zd;
       if (!(n <= max_n[k])) max_n[k] = n;
+      if (!a.seg(k).cubic) { // the exponent the certified evaluation hands to exp's main branch (refr_n_layer3): |e| <= 700 required
+        const double e = a.seg(k).lapse != 0.0 ? a.seg(k).expo * dm_log(t / a.seg(k).tb) : a.seg(k).expo * (h - a.seg(k).hb);
+        const double ae = e < 0.0 ? -e : e;
+        if (!(ae <= max_abs_e[k])) max_abs_e[k] = ae;
+      }
     }
   }
   return 0;

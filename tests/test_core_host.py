@@ -107,11 +107,11 @@ WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
 def _certify(core, atm, spherical=True, radius=6371000.0, step=50.0, wavelength=530e-9):
     n = C.c_int(0)
     cap = sum(atm.functions[j].n_points + 1 if atm.functions[j].kind == 1 else 1 for j in range(atm.n_functions))  # most segments the table can have
-    arrs = [np.zeros(cap) for _ in range(7)]
+    arrs = [np.zeros(cap) for _ in range(8)]
     band = np.zeros(2)
     assert core.ch_certify(C.byref(atm), C.c_double(wavelength), int(spherical), C.c_double(radius), C.c_double(step), C.byref(n),
-                           ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(band), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(arrs[6])) == 0
-    keys = ("from", "safe_lo", "safe_hi", "min_t", "max_pt", "max_z_dev", "max_n")
+                           ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(band), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(arrs[6]), ptr(arrs[7])) == 0
+    keys = ("from", "safe_lo", "safe_hi", "min_t", "max_pt", "max_z_dev", "max_n", "max_abs_e")
     return {k: a[:n.value] for k, a in zip(keys, arrs)}, band
 
 
@@ -127,6 +127,7 @@ def test_certified_intervals_cover_the_standard_atmosphere(core):
     assert band[0] == -100000.0 and band[1] == 1.0e7
     # an independent dense sample of the certified intervals stays far inside the shortcuts' range
     assert c["min_t"].min() >= 1.0 and c["max_z_dev"].max() <= 0.5 and c["max_n"].max() < 2.0 and c["max_pt"].max() < 2.0e5
+    assert c["max_abs_e"].max() <= 650.0  # exp's main branch (|e| <= 700) needs no range vote inside a certified interval
     # a planet of 10 km: the band ends 1 km above its centre; a radius, step or wavelength outside the supported span: nothing certified
     c, band = _certify(core, config.us76(), radius=10000.0)
     assert band[0] == -9000.0 and c["safe_lo"][0] == -9000.0
@@ -149,7 +150,7 @@ def test_a_spline_that_overshoots_is_certified_only_where_it_is_tame(core):
     assert c["safe_lo"][1] == -500.0 and 2000.0 < c["safe_hi"][1] < 4000.0, "the first knot interval: only below the point where T falls to 1 K"
     assert not certified[2] and not certified[3] and not certified[4], "their base pressure has overflowed already"
     for k in np.flatnonzero(certified):
-        assert c["min_t"][k] >= 1.0 and c["max_z_dev"][k] <= 0.5 and c["max_n"][k] < 2.0
+        assert c["min_t"][k] >= 1.0 and c["max_z_dev"][k] <= 0.5 and c["max_n"][k] < 2.0 and c["max_abs_e"][k] <= 650.0
     # a physical spline (troposphere + inversion) is certified knot to knot
     tame = {"pressure": {"altitude": 0.0, "pressure": 101325.0}, "first_temperature_function": {"Spline": {"boundary_condition": "Natural",
             "points": [[0.0, 288.0], [1000.0, 283.0], [1200.0, 285.0], [5000.0, 260.0], [11000.0, 217.0], [20000.0, 217.0]]}}}
@@ -193,6 +194,7 @@ def test_certificates_of_random_atmospheres_hold_on_a_dense_sample(core, block):
             n_certified += 1
             # (the interval ends are found by bisection on the bounds: allow their rounding)
             assert c["min_t"][k] >= 1.0 - 1e-9 and c["max_z_dev"][k] <= 0.5 + 1e-9 and 1.0 <= c["max_n"][k] <= 257.0, (atm, k)
+            assert c["max_abs_e"][k] <= 650.0, (atm, k)
             assert band[0] <= c["safe_lo"][k] and c["safe_hi"][k] <= band[1]
             if k > 0:
                 assert c["safe_lo"][k] >= c["from"][k]

@@ -20,6 +20,17 @@ namespace atmrt {
 // Each ray therefore gets an OCTET of lanes: lanes 0-2 serve stages 1 and 3, lanes 4-6 stages 2 and 4 (lanes 3 and 7
 // duplicate); values are exchanged with shuffles and the cheap remainder is computed redundantly by all eight lanes.
 // Same operations in the same order per value; a quarter of the dependent chain of the one-lane-per-ray version.
+// Data movement inside an octet without LDS: a DPP `quad_perm` broadcast hands lane k of every quad to the quad's four lanes, and
+// `row_half_mirror` (lane i <-> lane 7 - i of each half row = octet) hands a value that is uniform within each quad to the other
+// quad.  VALU-speed moves on the dependent chain where __shfl (ds_bpermute: an LDS round trip) used to be.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST1 = 0x55, DPP_QUAD_BCAST2 = 0xAA, DPP_ROW_HALF_MIRROR = 0x141;
+
 template <bool CUBIC>
 struct OctetRK4 {
   const AtmTable& atm;
@@ -34,13 +45,17 @@ struct OctetRK4 {
     const int e = sub & 3;
     const double hh = e == 1 ? h - eps : e == 2 ? h + eps : h;
     const double nv = refr_n_speculative<CUBIC>(atm, hh, hint, certified);
-    n_a = __shfl(nv, base, 64);
-    const double a1 = __shfl(nv, base + 1, 64), a2 = __shfl(nv, base + 2, 64);
-    n_b = __shfl(nv, base + 4, 64);
-    const double b1 = __shfl(nv, base + 5, 64), b2 = __shfl(nv, base + 6, 64);
+    // every lane of a quad: its quad's n(h), n(h - eps), n(h + eps); then dn for the quad's stage, then the other quad's pair
+    const double n_q = dpp_move<DPP_QUAD_BCAST0>(nv);
+    const double q1 = dpp_move<DPP_QUAD_BCAST1>(nv), q2 = dpp_move<DPP_QUAD_BCAST2>(nv);
     // shortcut divisions whether or not every lane was certified: next() discards the step if one was not
-    dn_a = dm_div(a2 - a1, 2.0 * eps);
-    dn_b = dm_div(b2 - b1, 2.0 * eps);
+    const double dn_q = dm_div(q2 - q1, 2.0 * eps);
+    const double n_o = dpp_move<DPP_ROW_HALF_MIRROR>(n_q), dn_o = dpp_move<DPP_ROW_HALF_MIRROR>(dn_q);
+    const bool second = (sub & 4) != 0; // this lane's quad serves stage group b
+    n_a = second ? n_o : n_q;
+    dn_a = second ? dn_o : dn_q;
+    n_b = second ? n_q : n_o;
+    dn_b = second ? dn_q : dn_o;
   }
   static __device__ __forceinline__ double accel(bool spherical, double a, double b, double n, double dn) {
     return accel_rhs<true>(spherical, a, b, n, dn);

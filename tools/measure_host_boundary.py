@@ -13,10 +13,7 @@ sys.path.insert(0, ROOT)
 from atm_raytracer_amd import _abi, generators, synth  # noqa: E402
 
 
-def main():
-    out = {}
-    ctx = generators.Context(0)
-    cfg, tiles = synth.scene("headline", level=2)
+def measure(ctx, cfg, tiles, out, suffix=""):
     terrain = generators.Terrain.from_tiles(tiles, ctx)
     for name in ("Rectilinear", "Fast"):
         cfg.params.generator = _abi.GENERATORS[name]
@@ -35,9 +32,21 @@ def main():
             if it:
                 times.append(dt)
         wall = sum(times) / len(times)
-        out[name] = {"wall_ms": wall * 1e3, "device_ms": dev_ms, "result_bytes": int(nbytes), "ray_steps": int(steps),
+        out[name + suffix] = {"wall_ms": wall * 1e3, "device_ms": dev_ms, "result_bytes": int(nbytes), "ray_steps": int(steps),
                      "ray_steps_per_s_pcie_inclusive": steps / wall, "ray_steps_per_s_device": steps / (dev_ms * 1e-3)}
+    if suffix:
+        out["comm" + suffix] = ctx.comm_timings()
     ctx.close()
+
+
+def main():
+    out = {}
+    cfg, tiles = synth.scene("headline", level=2)
+    measure(generators.Context(0), cfg, tiles, out)
+    # the multi-device route of atmrt_generate (csrc/atmrt_multi.hip) with two sub-contexts on the ONE GPU of this box: the two
+    # tiles share the device, so the device time is that of the whole frame; what the line shows is the cost of the host-side
+    # assembly (strided plane copies + the merge of the trace-point lists on two host threads) on top of it
+    measure(generators.Context.multi([0, 0]), cfg, tiles, out, suffix="_two_tiles_one_gpu")
     print(json.dumps(out))
 
 

@@ -443,6 +443,54 @@ def test_randomised_extremes(gpu_ctx, oracle_det, seed):
     assert np.array_equal(generators.draw_image(gpu_ctx, col, got["width"], got["height"]), oracle_det.draw_image(want, ocol))
 
 
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("ATMRT_LONG_ATM_SEEDS", "30"))))
+def test_randomised_long_atmospheres(gpu_ctx, oracle_det, seed):
+    """A fourth seeded sweep, for what ABI 4 made possible: atmosphere definitions far beyond the old capacities (8 functions, 32
+    knots, 64 segments) — 9 .. 70 temperature functions, Linear ones and Splines of 2 .. 120 knots mixed, thin and thick layers,
+    lapse rates of either sign — through all three generators (frames of a few hundred pixels, rays that climb through many
+    segments) and through the sampler harness at every segment boundary.  The table is header + records in HBM with a bisection
+    layer search; the certificate runs over every segment.  GPU == oracle in every bit."""
+    from atm_raytracer_amd import config, generators
+    rng = np.random.default_rng(900_000 + seed)
+    n_fn = int(rng.integers(9, 71)) if rng.uniform() < 0.7 else int(rng.integers(1, 4))
+    tops = np.sort(rng.uniform(0.0, 45_000.0, n_fn - 1)) + np.arange(n_fn - 1) * 0.5
+    functions, t_here = [], float(rng.uniform(270.0, 310.0))
+    for j in range(n_fn):
+        lo = -2000.0 if j == 0 else float(tops[j - 1])
+        hi = float(tops[j]) if j < n_fn - 1 else lo + float(rng.uniform(2000.0, 30_000.0))
+        if rng.uniform() < (0.25 if n_fn > 3 else 0.9):  # a Spline over (and a little beyond) this function's range
+            n_k = int(rng.integers(2, 121 if n_fn <= 3 else 25))
+            ks = np.sort(rng.uniform(lo - 50.0, hi + 50.0, n_k)) + np.arange(n_k) * 1e-2
+            ts = np.clip(t_here - 0.005 * (ks - lo) + rng.normal(0.0, 1.0, n_k), 150.0, 340.0)
+            functions.append({"Spline": {"boundary_condition": "Natural", "points": [[float(a), float(t)] for a, t in zip(ks, ts)]}})
+            t_here = float(ts[-1])
+        else:
+            g = float(rng.choice([-0.0065, 0.0, 0.003, -0.0098, float(rng.uniform(-0.012, 0.012))]))
+            functions.append({"Linear": {"gradient": g}})
+            t_here = float(np.clip(t_here + g * (hi - max(lo, 0.0)), 160.0, 330.0))
+    atm = {"pressure": {"altitude": float(rng.uniform(0.0, 1500.0)), "pressure": float(rng.uniform(700.0, 1050.0)) * 100.0},
+           "temperature_fixed_point": {"altitude": float(rng.uniform(0.0, 3000.0)), "temperature": float(rng.uniform(250.0, 300.0))},
+           "first_temperature_function": functions[0],
+           "next_functions": [{"altitude": float(a), "function": f} for a, f in zip(tops, functions[1:])]}
+    gen = ["Fast", "Rectilinear", "InterpolatingRectilinear"][seed % 3]
+    w, h = (int(rng.integers(8, 40)), int(rng.integers(6, 24))) if gen != "Rectilinear" else (int(rng.integers(4, 20)), int(rng.integers(4, 14)))
+    cfg, tiles = synth.scene("S2", w, h, generator=gen, atmosphere=atm, tilt=float(rng.uniform(-3.0, 25.0)), fov=float(rng.uniform(2.0, 60.0)),
+                             max_distance=float(rng.uniform(20_000.0, 150_000.0)), step=float(rng.choice([50.0, 100.0, 400.0])),
+                             terrain_alpha=float(rng.choice([1.0, 0.5])))
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+    env = oracle_det.env(cfg.atmosphere, cfg.params.wavelength)
+    edges = np.array([env.from_[k] for k in range(env.n)])
+    alt = np.concatenate([edges, np.nextafter(edges, -np.inf), edges + 0.01, rng.uniform(-3000.0, 80_000.0, 200)])
+    s = generators.atmosphere_sample(gpu_ctx, alt)
+    for i, a in enumerate(alt):
+        for key, fn in (("temperature", oracle_det.temperature), ("pressure", oracle_det.pressure), ("n", oracle_det.n), ("dn_dh", oracle_det.dn)):
+            x, y = s[key][i], fn(env, a)
+            assert x == y or (x != x and y != y), (key, a, x, y)
+    import ctypes as C
+    gpu_ctx.check(gpu_ctx.lib.atmrt_set_atmosphere(gpu_ctx.handle, C.byref(config.us76())))
+
+
 @pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("ATMRT_HARNESS_SEEDS", "40"))))
 def test_randomised_harnesses(gpu_ctx, oracle_det, seed):
     """The diagnostic entry points (output-atm, output-ray-paths, DirectionalCalc::coords_at_dist: src/atm_printer.rs:37-46,

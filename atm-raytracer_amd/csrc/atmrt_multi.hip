@@ -160,20 +160,35 @@ struct MultiGroup {
   std::vector<ncclComm_t> nccl;
   atmrt_comm_timings_t tm{};
 
-  void barrier() {
+  bool aborted = false; // a device failed inside a task that has barriers: the others stop waiting (guarded by bm)
+
+  // All devices meet here; false: one of them failed since the task began, and nobody waits any more.
+  bool barrier() {
     std::unique_lock<std::mutex> lk(bm);
+    if (aborted) return false;
     const uint64_t gen = bgen;
     if (++bcount == (int)kids.size()) {
       bcount = 0;
       bgen++;
       bcv.notify_all();
     } else {
-      bcv.wait(lk, [&] { return bgen != gen; });
+      bcv.wait(lk, [&] { return bgen != gen || aborted; });
     }
+    return !aborted;
+  }
+  void abort_task() {
+    std::lock_guard<std::mutex> lk(bm);
+    aborted = true;
+    bcv.notify_all();
   }
 
   // Runs fn(child, index) on every device's own host thread and waits; returns the first failure.
   int run(const std::function<int(atmrt_ctx*, int)>& fn) {
+    {
+      std::lock_guard<std::mutex> bl(bm); // every worker is idle here: a fresh barrier for the new task
+      aborted = false;
+      bcount = 0;
+    }
     std::unique_lock<std::mutex> lk(m);
     task = &fn;
     pending = (int)kids.size();
@@ -200,6 +215,7 @@ struct MultiGroup {
         fn = task;
       }
       const int r = (*fn)(kids[i], i);
+      if (r) abort_task(); // peers that wait for this device at a barrier of the same task give up instead of hanging
       {
         std::lock_guard<std::mutex> lk(m);
         rc[i] = r;
@@ -357,14 +373,19 @@ int comm_all_gather(atmrt_ctx* c, const void* send, void* recv, size_t bytes) {
       // one process: every device writes its tile into every peer's buffer.  A failing rank still passes both barriers.
       MultiGroup* g = cm->group;
       g->recv_ptr[(size_t)cm->rank] = recv;
-      g->barrier(); // every buffer is published, and no peer still reads what is about to be overwritten
+      if (!g->barrier()) // every buffer is published, and no peer still reads what is about to be overwritten
+        return c->fail(ATMRT_ERR_STATE, "another device of the context failed during this frame");
       hipError_t e = hipSuccess;
       for (int q = 0; q < cm->world && e == hipSuccess; q++)
         e = hipMemcpyPeerAsync(static_cast<char*>(g->recv_ptr[(size_t)q]) + (size_t)cm->rank * bytes, g->devices[(size_t)q], send,
                                c->device, bytes, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
-      g->barrier(); // every tile has landed everywhere
-      if (e != hipSuccess) return c->fail(ATMRT_ERR_HIP, "peer copy of a tile failed: %s", hipGetErrorString(e));
+      if (e != hipSuccess) {
+        g->abort_task();
+        return c->fail(ATMRT_ERR_HIP, "peer copy of a tile failed: %s", hipGetErrorString(e));
+      }
+      if (!g->barrier()) // every tile has landed everywhere
+        return c->fail(ATMRT_ERR_STATE, "another device of the context failed during this frame");
       return ATMRT_OK;
     }
     case ATMRT_ROUTE_EXTERNAL: {
@@ -728,6 +749,16 @@ extern "C" int atmrt_ctx_create_multi(atmrt_ctx** out, const int32_t* devices, i
       atmrt_ctx_destroy(parent);
       return api_create_fail(ATMRT_ERR_HIP, "ATMRT_GATHER=rccl: " + why);
     }
+  }
+  if (n > 1 && g->kids[0]->comm->route == ATMRT_ROUTE_PEER) { // direct device-to-device copies where the topology allows them
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        int can = 0;
+        if (devices[i] == devices[j] || hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) continue;
+        if (hipSetDevice(devices[i]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+        (void)hipGetLastError(); // "already enabled" is fine
+      }
+    (void)hipSetDevice(devices[0]);
   }
   for (int i = 0; i < n; i++) g->workers.emplace_back([g, i] { g->worker(i); });
   *out = parent;

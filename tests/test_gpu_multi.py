@@ -234,6 +234,16 @@ def test_multi_context_errors_and_recovery(gpu_ctx, multi3):
         run_gpu(multi3, cfg, tiles)
     assert "device" in str(e.value) and "injected" in str(e.value)
     assert_bitexact(run_gpu(multi3, cfg, tiles), want)
+    # the same on the device route: the frame fails before any exchange starts (nobody waits for the device that failed) ...
+    gen = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, multi3))
+    images = [generators.image_planes(24, 60, torch.device("cuda", 0)) for _ in range(3)]
+    multi3.check(multi3.lib.atmrt_debug_fail_next_frame(multi3.handle))
+    with pytest.raises(generators.AtmrtError) as e:
+        gen.generate_image_device([pod for _, pod in images])
+    assert "injected" in str(e.value)
+    gen.generate_image_device([pod for _, pod in images])  # ... and the next frame is whole again
+    for planes, _ in images:
+        check_image(planes, want)
     # the device-only entry points of a plain context are refused on a multi-device one
     planes, pod = generators.image_planes(24, 60, torch.device("cuda", 0))
     assert multi3.lib.atmrt_generate_device(multi3.handle, C.byref(pod), None, None) == _abi.ERR_STATE

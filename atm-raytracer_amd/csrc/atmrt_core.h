@@ -363,6 +363,9 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
     tmax += 1.0e-6 * (dm_fabs(tmin) + dm_fabs(tmax)) + 1.0e-6;
     if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
     pmax = pb;
+    // p / pb = exp(e), e = expo * (integral of dh / T) in [expo d1 / tmin, 0]: at least -640, so that the certified evaluation may
+    // call the main branch of exp unasked here too (refr_n_layer_inrange)
+    if (!(t.seg(k).expo * d1 / tmin >= -640.0)) return false;
     pmin = pb * dm_exp(t.seg(k).expo * d1 / tmin); // expo < 0
   } else {
     if (t.seg(k).lapse != 0.0 && !(dm_fabs(t.seg(k).expo) <= 1.0e6)) return false; // a lapse rate below 4e-8 K/m: the exponent of pow runs away
@@ -599,27 +602,57 @@ ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   return (n2 - n1) / (2.0 * eps);
 }
 
+// Environment::n(h) for a point INSIDE the certified part of its segment: shortcut divisions, and log / exp by their main branches
+// without range tests (atm_interval_certified bounds T / tb to a positive normal number and the exponent to |e| <= 645).
+// Straight-line code.  For a point outside, the result is garbage of no consequence (every table index is masked): callers
+// discard it (refr_n_speculative's `certified` flag).
+template <bool CUBIC>
+ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3,
+                                     double expo, double h) {
+  if (CUBIC && cubic) {
+    const double temp = seg_temperature(tb, lapse, c2, c3, h - hb);
+    const double p = pb * dm_exp_main(expo * seg_inv_t_integral(tb, lapse, c2, c3, h - hb));
+    return refr_from_tp<true>(k_refr, temp, p);
+  }
+  const double temp = tb + lapse * (h - hb);
+  const double e = lapse != 0.0 ? expo * dm_log_core_pow(dm_div(temp, tb)) : expo * (h - hb);
+  return refr_from_tp<true>(k_refr, temp, pb * dm_exp_main(e));
+}
+
 // One evaluation of n(h) with the shortcut divisions, organised for the wavefront of the path kernel (atmrt_paths.hip): `hint` is the
 // layer of the lane's previous evaluation.  When every active lane is inside the certified part of the first lane's layer (rays
-// below 11 km in a physical atmosphere) the layer search is two compares and the layer parameters are wave-uniform scalars;
-// otherwise every lane makes the full search and gathers its own parameters (eight rays of different elevations share a wavefront
-// there: the normal case above 11 km).  `certified` (per lane): the point lies in the certified part of its layer, i.e. the value is
-// refr_n's.  If it is false the value is NOT to be used — the caller verifies the flags of a whole step with one vote and repeats
-// the step with IEEE operations when one is false.  GPU only.
+// below 11 km in a physical atmosphere) the layer search is two compares and the layer parameters are wave-uniform scalars —
+// kept in `cache` (SGPRs) from one evaluation to the next and re-read only when the hinted layer changes, so that no scalar-load
+// round trip sits on the kernel's dependent chain; otherwise every lane makes the full search and gathers its own parameters
+// (eight rays of different elevations share a wavefront there: the normal case above 11 km).  `certified` (per lane): the point
+// lies in the certified part of its layer, i.e. the value is refr_n's.  If it is false the value is NOT to be used — the caller
+// verifies the flags of a whole step with one vote and repeats the step with IEEE operations when one is false.  GPU only.
 #if defined(__HIPCC__)
+struct AtmLayerCache {
+  int k = -1;
+  int cubic = 0;
+  double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
+};
 template <bool CUBIC>
-__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, double h, int& hint, bool& certified) {
+__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified) {
   const int ku = __builtin_amdgcn_readfirstlane(hint);
-  const AtmConstTable ka = atm_const_table(a);
-  const AtmConstSeg ks = atm_const_seg(a, ku);
-  if (__all(h >= ks->safe_lo && h < ks->safe_hi)) {
+  if (ku != cache.k) { // wave-uniform
+    const AtmConstSeg ks = atm_const_seg(a, ku);
+    cache.k = ku;
+    cache.cubic = ks->cubic;
+    cache.safe_lo = ks->safe_lo, cache.safe_hi = ks->safe_hi, cache.hb = ks->hb, cache.tb = ks->tb, cache.pb = ks->pb;
+    cache.lapse = ks->lapse, cache.c2 = ks->c2, cache.c3 = ks->c3, cache.expo = ks->expo;
+    cache.k_refr = atm_const_table(a)->k_refr;
+  }
+  if (__all(h >= cache.safe_lo && h < cache.safe_hi)) {
     certified = true;
-    return refr_n_layer<CUBIC, true>(ka->k_refr, ks->cubic, ks->hb, ks->tb, ks->pb, ks->lapse, ks->c2, ks->c3, ks->expo, h);
+    return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
   }
   const int k = atm_layer(a, h);
   hint = k;
-  certified = h >= a.seg(k).safe_lo && h < a.seg(k).safe_hi;
-  return refr_n_layer<CUBIC, true>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+  const AtmSeg& sg = a.seg(k);
+  certified = h >= sg.safe_lo && h < sg.safe_hi;
+  return refr_n_layer_inrange<CUBIC>(a.k_refr, sg.cubic, sg.hb, sg.tb, sg.pb, sg.lapse, sg.c2, sg.c3, sg.expo, h);
 }
 #endif
 

@@ -157,6 +157,23 @@ __device__ __forceinline__ void stage_dm_tables() {
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Wavefront compaction (the ballot / prefix primitive BASELINE's north_star names, where this path has rays to compact: the rays and
+// pixels a second pass must visit): every lane with `take` appends `value` to list[*cursor ..] — ONE atomic per wavefront instead of
+// one per lane, the wavefront's entries contiguous and in lane order (v_mbcnt prefix count over the ballot).  Every lane of the
+// wavefront that is still running must call it (lanes that returned earlier are simply not in the ballot).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_compact_append(bool take, uint32_t value, uint32_t* __restrict__ list, unsigned long long* __restrict__ cursor) {
+  const unsigned long long m = __ballot(take);
+  if (!m) return; // wave-uniform
+  const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); // takers below this lane
+  const int leader = __builtin_ctzll(m);
+  unsigned long long base = 0;
+  if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(cursor, (unsigned long long)__builtin_popcountll(m));
+  base = __shfl(base, leader, 64);
+  if (take) list[base + rank] = value;
+}
+#endif
+
 // The DirectionalCalc kind is a compile-time constant in the heavy kernels, so only one of the four
 // calculators (AzEq / FlDs / Spherical / Ellipsoid-Vincenty) is instantiated per kernel variant.
 template <int CALC>

@@ -179,7 +179,10 @@ void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, h
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                        hipStream_t stream);
 void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream, int i_begin, int i_end); // atmrt_paths.hip
-constexpr int FAST_SEGMENTS = 4;
+#ifndef ATMRT_FAST_SEGMENTS
+#define ATMRT_FAST_SEGMENTS 4
+#endif
+constexpr int FAST_SEGMENTS = ATMRT_FAST_SEGMENTS;
 int launch_fast_pipeline(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
                          hipEvent_t ev_fork, hipEvent_t* ev_seg, hipEvent_t* ev_scan, hipEvent_t* timing); // returns the number of segments
 void launch_fast_caches(const Frame& f, Workspace& ws, hipStream_t stream, hipStream_t stream2, hipEvent_t ev,

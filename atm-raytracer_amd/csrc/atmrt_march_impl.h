@@ -588,12 +588,9 @@ static __global__ __launch_bounds__(256) void k_rect_gather_slots(Frame f, const
                                                            unsigned long long* __restrict__ counters) {
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= plane) return;
-  const uint32_t n = hit_count[p];
-  if (n > (uint32_t)RECT_SLOTS) {
-    overflow[atomicAdd(&counters[3], 1ull)] = (uint32_t)p;
-    return;
-  }
+  const uint32_t n = p < plane ? hit_count[p] : 0u;
+  wave_compact_append(n > (uint32_t)RECT_SLOTS, (uint32_t)p, overflow, &counters[3]); // the pixels the second march visits
+  if (p >= plane || n > (uint32_t)RECT_SLOTS) return;
   const uint64_t k = hit_offset[p];
   for (uint32_t j = 0; j < n; j++) {
     const size_t q = (size_t)j * plane + p;
@@ -632,7 +629,7 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
 static __global__ __launch_bounds__(256) void k_collect_object_rays(size_t n, const uint32_t* __restrict__ hit_count,
                                                                     uint32_t* __restrict__ list, unsigned long long* __restrict__ counters) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n && hit_count[p] == OBJECT_RAY) list[atomicAdd(&counters[11], 1ull)] = (uint32_t)p;
+  wave_compact_append(p < n && hit_count[p] == OBJECT_RAY, (uint32_t)p, list, &counters[11]); // the rays the general tracer visits
 }
 
 // Scenes with objects, counting pass, phase 1: the lean march over every pixel (terrain crossings into the tracer's slot arena,
@@ -669,12 +666,9 @@ static __global__ __launch_bounds__(256) void k_rect_gather_trace_slots(Frame f,
                                                                         unsigned long long* __restrict__ counters) {
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= plane) return;
-  const uint32_t n = hit_count[p];
-  if (n > (uint32_t)RECT_SLOTS) {
-    overflow[atomicAdd(&counters[3], 1ull)] = (uint32_t)p;
-    return;
-  }
+  const uint32_t n = p < plane ? hit_count[p] : 0u;
+  wave_compact_append(n > (uint32_t)RECT_SLOTS, (uint32_t)p, overflow, &counters[3]); // the pixels the tracer's fill pass visits
+  if (p >= plane || n > (uint32_t)RECT_SLOTS) return;
   const uint64_t k0 = hit_offset[p];
   for (uint32_t j = 0; j < n; j++) {
     const size_t q = p * RECT_SLOTS + j;

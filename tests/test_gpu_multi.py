@@ -216,6 +216,31 @@ def test_external_transport_two_ranks_in_two_threads(gpu_ctx):
         assert tm["route"] == "external" and tm["world"] == 2
 
 
+@pytest.mark.parametrize("generator", GENERATORS)
+def test_multi_context_degenerate_frames(gpu_ctx, multi3, generator):
+    """Frames at the edges of the tiling: a sky-only view (no trace point anywhere: empty lists on every device) and an image exactly
+    as wide as the number of devices (one pixel column per tile)."""
+    sky, tiles = synth.scene("S2", 64, 20, generator=generator, tilt=60.0, fov=20.0, max_distance=30_000.0)
+    want = run_gpu(gpu_ctx, sky, tiles)
+    assert want["n_hits"] == 0
+    got = run_gpu(multi3, sky, tiles)
+    got["ray_steps"] = want["ray_steps"] if generator == "InterpolatingRectilinear" else got["ray_steps"]
+    assert_bitexact(got, want)
+    thin, tiles = synth.scene("S2", 3, 17, generator=generator, tilt=-3.0, max_distance=40_000.0, terrain_alpha=0.5)
+    want = run_gpu(gpu_ctx, thin, tiles)
+    assert want["n_hits"] > 0
+    got = run_gpu(multi3, thin, tiles)
+    got["ray_steps"] = want["ray_steps"] if generator == "InterpolatingRectilinear" else got["ray_steps"]
+    assert_bitexact(got, want)
+    images = [generators.image_planes(17, 3, torch.device("cuda", 0)) for _ in range(3)]
+    gen = generators.make_generator(generators.Params(thin), generators.Terrain.from_tiles(tiles, multi3))
+    gen.generate_image_device([pod for _, pod in images])
+    for planes, _ in images:
+        check_image(planes, want)
+    for h in gen.image_hits_device(17, 3):
+        check_lists(h, want)
+
+
 def test_multi_context_errors_and_recovery(gpu_ctx, multi3):
     cfg, tiles = scene("Fast", False, width=60, height=24)
     # the library assigns the tiles: a caller's own column shard is refused

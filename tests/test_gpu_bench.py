@@ -23,8 +23,8 @@ def run_bench(*args, env=None, timeout=600):
     return json.loads(lines[0]), p.stderr
 
 
-@pytest.mark.parametrize("generator,extra", [("Rectilinear", []), ("Fast", ["--terrain-alpha", "0.5", "--objects", "40"])],
-                         ids=["rect-opaque", "fast-lists"])
+@pytest.mark.parametrize("generator,extra", [("Rectilinear", []), ("Fast", ["--terrain-alpha", "0.5", "--objects", "40"]), ("Fast", [])],
+                         ids=["rect-opaque", "fast-lists", "fast-opaque"])
 def test_bench_gpus_2_launches_two_ranks(generator, extra):
     line, err = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "512", "--height", "256", "--dted-level", "1",
                           "--no-cpu-baseline", "--only", "--generator", generator, *extra,

@@ -163,6 +163,16 @@ def test_image_in_hbm_on_every_device(gpu_ctx, kind):
 def test_external_transport_two_ranks_in_two_threads(gpu_ctx):
     """atmrt_ctx_comm_init_external: two rank contexts on the one GPU, driven by two host threads; the host's all-gather is a
     test double (a barrier and a shared buffer).  The path an MPI or gloo host takes."""
+    return _two_rank_threads(gpu_ctx, "Rectilinear", True)
+
+
+def test_external_transport_fast_generator(gpu_ctx):
+    """The Fast generator (opaque frame: first-hit planes only, no lists) through the host transport, two rank threads, an odd
+    number of rows."""
+    return _two_rank_threads(gpu_ctx, "Fast", False)
+
+
+def _two_rank_threads(gpu_ctx, generator, lists):
     world = 2
     barrier = threading.Barrier(world)
     shared = {}
@@ -182,7 +192,7 @@ def test_external_transport_two_ranks_in_two_threads(gpu_ctx):
             barrier.wait()
         return all_gather
 
-    cfg, tiles = scene("Rectilinear", True, width=70, height=30)
+    cfg, tiles = scene(generator, lists, width=70, height=31)
     W, H = cfg.params.width, cfg.params.height
     want = run_gpu(gpu_ctx, cfg, tiles)
     results, errors = {}, []
@@ -191,11 +201,11 @@ def test_external_transport_two_ranks_in_two_threads(gpu_ctx):
         try:
             ctx = generators.Context(0)
             ctx.comm_init_external(rank, world, transport(rank))
-            cfg_r, _ = scene("Rectilinear", True, width=70, height=30)
+            cfg_r, _ = scene(generator, lists, width=70, height=31)
             gen = generators.make_generator(generators.Params(cfg_r), generators.Terrain.from_tiles(tiles, ctx))
             planes, pod = generators.image_planes(H, W, torch.device("cuda", 0))
             steps, _ = gen.generate_image_device(pod)
-            hits = gen.image_hits_device(H, W)
+            hits = gen.image_hits_device(H, W) if lists else None
             results[rank] = (planes, hits, steps, ctx.comm_timings())
             ctx.close()
         except Exception as exc:  # noqa: BLE001
@@ -212,7 +222,8 @@ def test_external_transport_two_ranks_in_two_threads(gpu_ctx):
     for r in range(world):
         planes, hits, _, tm = results[r]
         check_image(planes, want)
-        check_lists(hits, want)
+        if lists:
+            check_lists(hits, want)
         assert tm["route"] == "external" and tm["world"] == 2
 
 

@@ -223,7 +223,7 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
                     &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
                     &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand, &c->d_path_seg, &c->d_dprev, &c->d_step_prop, &c->d_blend_arena,
-                    &c->d_object_rays})
+                    &c->d_object_rays, &c->d_slice})
     b->release(); // (a buffer missing from this list is released by its destructor when the context is deleted below)
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -662,6 +662,12 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->list_pixel = nullptr;
   ws->step_prop = nullptr;
   ws->object_rays = nullptr;
+  ws->slice_state = nullptr;
+  SliceLayout slices;
+  if (f.n_objects == 0 && march_slice_layout(f, slices)) { // a small Rectilinear launch over opaque terrain: the time-sliced march
+    HIP_TRY(c, c->d_slice.reserve(slices.bytes));
+    ws->slice_state = c->d_slice.as<char>();
+  }
   return ATMRT_OK;
 }
 
@@ -996,6 +1002,8 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     c->timings = t;
   }
   (void)fast;
+  if (counters[12])
+    return c->fail(ATMRT_ERR_HIP, "the time-sliced march left %llu of its ray groups unfinished", (unsigned long long)counters[12] - 1);
   c->stats.unlisted_rays = counters[4];
   c->stats.unlisted_columns = counters[5];
   c->stats.big_steps = counters[6];

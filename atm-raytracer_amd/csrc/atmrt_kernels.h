@@ -2,6 +2,9 @@
 // kernels (atmrt_kernels.hip).  Internal; the public surface is include/atmrt.h.
 #pragma once
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "atmrt_core.h"
 #include "atmrt_objects.h"
 
@@ -82,11 +85,46 @@ struct PathSegState {
 // [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
 // together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march,
 // [11] rays of a scene with objects that the lean march left to the general tracer
-constexpr int N_COUNTERS = 12;
+constexpr int N_COUNTERS = 13; // [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks)
 
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
 constexpr int RECT_SLOTS = 4;
+
+// The time-sliced march of small Rectilinear launches (atmrt_march_impl.h, k_rect_march_first / _cont): which launches take it and
+// what they need.  A launch of at most MARCH_SMALL_MAX_BLOCKS 256-thread blocks is "small" (a few resident sets: column shards of a
+// frame, test frames); ATMRT_MARCH_VARIANT=plain|small|sliced forces one variant for every launch (test hook: the random sweeps run
+// small frames over the kernel the full-size frames use, and the other way round; same results every way).
+constexpr unsigned MARCH_SMALL_MAX_BLOCKS = 16384u;
+constexpr int MARCH_SLICE_STEPS = 128;
+static inline int march_variant_override() {
+  static const int v = [] {
+    const char* e = getenv("ATMRT_MARCH_VARIANT");
+    return !e ? 0 : !strcmp(e, "plain") ? 1 : !strcmp(e, "small") ? 2 : !strcmp(e, "sliced") ? 3 : 0;
+  }();
+  return v;
+}
+struct SliceLayout {
+  uint32_t n_groups;     // groups of 64 consecutive pixels
+  size_t n_pad;          // pixels rounded up to whole groups
+  size_t slices_after;   // an upper bound on the slices a ray can need after the first
+  size_t cap;            // FIFO entries: n_groups x slices_after
+  size_t bytes;          // of Workspace::slice_state
+};
+// false: this frame's march is not sliced (not opaque-terrain-only, one slice long, too big, or forced otherwise)
+static inline bool march_slice_layout(const Frame& f, SliceLayout& L) {
+  const size_t n = (size_t)f.wl * f.h;
+  const int ov = march_variant_override();
+  if (f.p.generator != ATMRT_GEN_RECTILINEAR || !f.opaque || n == 0 || f.n_t + 2 <= MARCH_SLICE_STEPS) return false;
+  if (ov ? ov != 3 : (n + 255) / 256 > MARCH_SMALL_MAX_BLOCKS) return false;
+  L.n_groups = (uint32_t)((n + 63) / 64);
+  L.n_pad = (size_t)L.n_groups * 64;
+  L.slices_after = ((size_t)f.n_t + 2 + MARCH_SLICE_STEPS - 1) / MARCH_SLICE_STEPS;
+  L.cap = (size_t)L.n_groups * L.slices_after;
+  if (L.cap > 0x7fffffffull) return false; // (a frame of > 2^31 slices is marched whole)
+  L.bytes = L.n_pad * (7 * sizeof(double) + 2 * sizeof(int32_t) + sizeof(DirCalc)) + 64 + L.cap * sizeof(uint32_t);
+  return true;
+}
 
 struct Workspace {
   double* alt;            // [1]
@@ -128,6 +166,7 @@ struct Workspace {
   uint32_t* object_rays;  // Rectilinear, scenes with objects: pixels the lean march left to the general tracer
   double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
+  char* slice_state;      // time-sliced march (march_slice_layout): ray state between two slices + the FIFO of groups, or null
 };
 
 // InterpolatingRectilinear scratch

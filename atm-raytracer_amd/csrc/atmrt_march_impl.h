@@ -60,28 +60,17 @@ constexpr int WAVE_CAND = 96;                // entries of a wavefront's list; m
 // 8 GPUs 41.5 -> 39.0 ms).  In a launch of many resident sets the drain is 1 % and the priorities cost about as much (the headline
 // frame 269.4 -> 271.6 ms), so only launches of at most DRAIN_PRIO_MAX_BLOCKS workgroups (16 resident sets) use them: the kernel is
 // compiled in both variants (DRAIN) and the launcher picks one by the size of its grid (ATMRT_LAUNCH_MARCH).
-#ifndef DRAIN_PRIO_MAX_BLOCKS
-#define DRAIN_PRIO_MAX_BLOCKS 16384u
-#endif
+constexpr unsigned DRAIN_PRIO_MAX_BLOCKS = MARCH_SMALL_MAX_BLOCKS;
 constexpr int DRAIN_PRIO_BAND = 512;
-// Test hook: ATMRT_MARCH_VARIANT=plain / small forces one variant for every launch, so that the random sweeps (small frames) can be
-// run over the kernel the full-size frames use, and the other way round.  Same results either way.
 #ifndef ATMRT_MARCH_BLOCK_SMALL
 #define ATMRT_MARCH_BLOCK_SMALL 256 // workgroup size of the small-launch (DRAIN) variant
 #endif
-static inline int march_variant_override() {
-  static const int v = [] {
-    const char* e = getenv("ATMRT_MARCH_VARIANT");
-    return !e ? 0 : !strcmp(e, "plain") ? 1 : !strcmp(e, "small") ? 2 : 0;
-  }();
-  return v;
-}
 // launches k_rect_march<MODE, CALC, CUBIC, DRAIN> over N rays / list entries, DRAIN by the grid size
 #define ATMRT_LAUNCH_MARCH(MODE, N, STREAM, ...)                                                                                       \
   do {                                                                                                                                 \
     const unsigned blocks_ = cdiv((size_t)(N), 256);                                                                                   \
     const int override_ = march_variant_override();                                                                                    \
-    if (override_ ? override_ == 2 : blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                               \
+    if (override_ ? override_ != 1 : blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                               \
       ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, true>),                                    \
                                                             dim3(cdiv((size_t)(N), ATMRT_MARCH_BLOCK_SMALL)), dim3(ATMRT_MARCH_BLOCK_SMALL), 0, STREAM, \
                                                             __VA_ARGS__));                                                             \
@@ -99,12 +88,21 @@ static inline int march_variant_override() {
 #ifndef ATMRT_MARCH_WAVES_SMALL
 #define ATMRT_MARCH_WAVES_SMALL 5
 #endif
+#ifdef ATMRT_TIMELINE
+// Experiment hook (tools/measure_march_timeline.py; never defined in the product build): start / end time and steps of every
+// wavefront of the last k_rect_march launch, read back through atmrt_debug_timeline.
+static __device__ unsigned long long g_timeline[3 * 65536 + 4 * 32768];
+static __device__ unsigned long long g_slices[4 * 262144 + 8]; // [0] = count; then {group | i0 << 32, start, end, wave | hw_id << 32}
+#endif
 template <int MODE, int CALC, bool CUBIC, bool DRAIN>
 __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMRT_MARCH_WAVES_SMALL : ATMRT_MARCH_WAVES) void k_rect_march(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
                                                     const uint32_t* __restrict__ pixel_list, uint32_t n_list) {
+#ifdef ATMRT_TIMELINE
+  const unsigned long long tl_t0 = wall_clock64();
+#endif
   stage_dm_tables();
   constexpr bool drain_prio = DRAIN;
   if (drain_prio) __builtin_amdgcn_s_setprio(3);
@@ -299,6 +297,305 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
       atomicAdd(&counters[10], lookups);
     }
   }
+#ifdef ATMRT_TIMELINE
+  if (MODE == 0 && (threadIdx.x & 63) == 0) {
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w < 65536) {
+      g_timeline[3 * w] = tl_t0;
+      g_timeline[3 * w + 1] = wall_clock64();
+      // steps | HW_ID[15:0] (wave, simd, pipe, cu, sh, se) << 24 | XCC_ID << 40
+      g_timeline[3 * w + 2] = steps | ((unsigned long long)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu) << 24) |
+                              ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) << 40);
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-sliced march (opaque terrain, no objects) for launches of a few resident sets: column shards of a frame.
+//
+// Why.  A shard of the headline at 8 GPUs is 16384 wavefronts of which 7688 march all 2000 steps: 1.5 resident sets of 5120.  The
+// hardware hands the second set to whichever CUs drain first (the wavefront timeline of such a launch, tools/
+// measure_march_timeline.py: 132 CUs take five more workgroups each, 124 take none and sit idle for the last 5 ms of 34), and no
+// order of the grid changes that.  Here the grid is PERSISTENT (one workgroup per resident slot) and a wavefront's unit of work is
+// a SLICE of a group of 64 rays: it takes the group's state from HBM, marches at most `slice` steps, puts the state back and
+// appends the group to the FIFO it took it from.  All groups thus advance together, the long ones end together in the last round
+// of slices, and the drain is one slice long instead of one ray long.  The state of a ray between two slices is 56 B (x, a, b,
+// the last sample's height, path length and ray-minus-terrain difference, step number, layer hint); direction, elevation and the
+// geodesic calculator are recomputed at the start of a slice (the same operations on the same inputs: the same bits).
+//
+// Queue: `ctl[0]` = pops claimed, `ctl[1]` = pushes claimed, `ctl[2]` = groups finished.  Pop number i < n_groups is group i's first
+// slice (no memory read); pop number n_groups + t is the t-th push, awaited in queue[t] (one reader per entry, entries never
+// reused: capacity = groups x slices per ray).  A wavefront waiting for its entry leaves when every group has finished; a
+// wavefront holding a group never waits, so the grid drains whatever part of it is resident.
+struct SliceState {
+  double *x, *a, *b, *sh, *pl, *diff0, *ang; // [plane]
+  int32_t *step, *hint;                      // [plane]; step < 0: the ray has finished
+  DirCalc* calc;                             // [plane] the ray's geodesic calculator
+  uint32_t* queue;                           // [cap], 0xffffffff = not pushed yet
+  unsigned long long* ctl;                   // [4]
+  uint32_t cap;
+};
+constexpr uint32_t SLICE_EMPTY = 0xffffffffu, SLICE_EXIT = 0xfffffffeu;
+#ifndef ATMRT_SLICE_WAVES
+#define ATMRT_SLICE_WAVES 4 // per SIMD: 128 VGPRs, no scratch (5 per SIMD measured equal: the slices hide the drain the fifth wave was for)
+#endif
+
+
+#ifdef ATMRT_TIMELINE
+static __device__ __forceinline__ int __reduce_max_sync_i0(int v) {
+  for (int o = 32; o; o >>= 1) {
+    const int u = __shfl_xor(v, o, 64);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+#endif
+// one slice of the march of a ray whose state is in registers; returns true when the ray is still marching after step i0 + slice
+template <int CALC, bool CUBIC, bool FAIR>
+static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& e, const DirCalc& c, Stepper& s, double& sh,
+                                                   double& path_length, double& diff0, double& re0, double& pl0, int i0, int slice,
+                                                   int& first, unsigned long long& steps, unsigned long long& lookups) {
+  const bool sph = e.spherical != 0;
+  const double radius = e.shape_radius;
+  const bool straight = f.p.straight_rays != 0;
+  const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
+  const double skip_above = f.tv.skip_above;
+  double sx = s.x, lat, lon;
+  const int i_end = i0 + slice;
+  const int quarter = slice >> 2;
+  for (int i = i0 + 1;; i++) {
+    if (FAIR) {
+      // The SIMD issues oldest-wavefront-first: left alone, the oldest persistent wavefront of a SIMD runs its slices at the speed of
+      // its dependency chain and the youngest gets what is left — nine times fewer slices, and the groups it holds fall rounds
+      // behind the others (they were the 4.5 ms tail of a 35 ms launch).  A slice therefore starts at priority 3 and gives way a
+      // level per quarter: whoever is behind within its slice runs first, the wavefronts of a SIMD take turns.
+      const int k = i - i0 - 1;
+      if (k == 0) __builtin_amdgcn_s_setprio(3);
+      else if (k == quarter) __builtin_amdgcn_s_setprio(2);
+      else if (k == 2 * quarter) __builtin_amdgcn_s_setprio(1);
+      else if (k == 3 * quarter) __builtin_amdgcn_s_setprio(0);
+    }
+    bool tame;
+    RayState nx = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
+    if (straight) tame = __all(calc_dist_in_band(*f.atm, sh) && calc_dist_in_band(*f.atm, nx.h));
+    path_length += calc_dist(sph, radius, sx, sh, nx.x, nx.h, tame);
+    sx = nx.x;
+    sh = nx.h;
+    if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) return false; // rectilinear.rs:178 (+ NaN guard)
+    double diff1 = 1.0; // above every post of the mosaic: see k_rect_march
+    if (!(sh > skip_above)) {
+      coords_at_dist(e, c, sx, lat, lon);
+      diff1 = sh - terrain_elev_or_zero(f.tv, lat, lon);
+      lookups++;
+    }
+    steps++;
+    if (diff0 * diff1 < 0.0) { // utils.rs:222; opaque terrain ends the march here (utils.rs:237-239)
+      first = i - 1;
+      return false;
+    }
+    diff0 = diff1;
+    re0 = sh;
+    pl0 = path_length;
+    if (i == i_end) return true;
+  }
+}
+
+template <int CALC>
+static __device__ __forceinline__ void slice_finish(const DensePlanes& out, int32_t* hit_step, const RectRec& rec, size_t p, int first,
+                                                    double re0, double pl0, double sh, double path_length) {
+  if (first >= 0) { // ray elevation and path length at the two samples that bracket the crossing
+    rec.re0[p] = re0;
+    rec.pl0[p] = pl0;
+    rec.re1[p] = sh;
+    rec.pl1[p] = path_length;
+  }
+  out.hit_count[p] = first >= 0 ? 1u : 0u;
+  hit_step[p] = first;
+}
+
+// wave-uniform end of a group's slice: announce the group again, or count it as finished
+static __device__ __forceinline__ void slice_requeue(const SliceState& st, uint32_t group, bool alive) {
+  const bool again = __any(alive);
+  if (again) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // state before the entry that announces it
+  if ((threadIdx.x & 63) == 0) {
+    if (again) {
+      const unsigned long long t = atomicAdd(&st.ctl[1], 1ull);
+      if (t < st.cap) __hip_atomic_store(st.queue + t, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      atomicAdd(&st.ctl[2], 1ull);
+    }
+  }
+}
+
+// slice 0 of every group: an ordinary grid (it is short: the launch drains in a fraction of a slice)
+template <int CALC, bool CUBIC>
+__global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+                                                                             RectRec rec, unsigned long long* __restrict__ counters,
+                                                                             SliceState st, uint32_t n_groups, int slice) {
+#ifdef ATMRT_TIMELINE
+  const unsigned long long tl_t0 = wall_clock64();
+#endif
+  stage_dm_tables();
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long steps = 0, lookups = 0;
+  bool alive = false;
+  if (p < plane) {
+    const Earth e = earth_for<CALC>(f);
+    const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
+    const double alt = *f.alt;
+    double direction, elevation;
+    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
+    DirCalc c;
+    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
+    Stepper s;
+    stepper_init(s, e.spherical != 0, e.shape_radius, alt, elevation);
+    out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
+    out.elevation_angle[p] = dm_to_degrees(elevation);
+    int first = -1;
+    double sh = alt, path_length = 0.0, re0 = alt, pl0 = 0.0, diff0 = 0.0;
+    if (!(0.0 > f.p.frame.max_distance || alt < -1000.0)) { // the reference would panic on an empty stream
+      double lat, lon;
+      coords_at_dist(e, c, 0.0, lat, lon);
+      diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
+      lookups++;
+      alive = march_slice<CALC, CUBIC, false>(f, e, c, s, sh, path_length, diff0, re0, pl0, 0, slice, first, steps, lookups);
+    }
+    if (alive) {
+      st.x[p] = s.x;
+      st.a[p] = s.a;
+      st.b[p] = s.b;
+      st.hint[p] = s.hint;
+      st.ang[p] = s.ang;
+      st.sh[p] = sh;
+      st.pl[p] = path_length;
+      st.diff0[p] = diff0;
+      st.step[p] = slice;
+      st.calc[p] = c;
+    } else {
+      st.step[p] = -1;
+      slice_finish<CALC>(out, hit_step, rec, p, first, re0, pl0, sh, path_length);
+    }
+  }
+  if ((p >> 6) < n_groups) slice_requeue(st, (uint32_t)(p >> 6), alive); // (the last block may hold wavefronts past the last group)
+  steps = wave_sum(steps);
+  lookups = wave_sum(lookups);
+#ifdef ATMRT_TIMELINE
+  if ((threadIdx.x & 63) == 0 && (p >> 6) < 32768) {
+    g_timeline[3 * (p >> 6)] = tl_t0;
+    g_timeline[3 * (p >> 6) + 1] = wall_clock64();
+    g_timeline[3 * (p >> 6) + 2] = steps;
+  }
+#endif
+  if ((threadIdx.x & 63) == 0 && steps) {
+    atomicAdd(&counters[0], steps);
+    atomicAdd(&counters[10], lookups);
+  }
+}
+
+// the later slices: one single-wavefront workgroup per queue entry.  NOT a persistent grid: the SIMD issues oldest-wavefront-first,
+// and persistent wavefronts keep their age order for the whole launch — the oldest of a SIMD ran its slices at the speed of its
+// dependency chain (0.57 ms), the youngest in 5 ms (measured, tools/measure_slice_timeline.py), groups that met the slow ones fell
+// five rounds behind and were a 4.5 ms tail; s_setprio did not change that.  A wavefront that lives for one slice starts youngest
+// and ends oldest: every slice sees every rank and the groups stay in step.
+template <int CALC, bool CUBIC>
+__global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
+                                                                           RectRec rec, unsigned long long* __restrict__ counters,
+                                                                           SliceState st, uint32_t n_groups, int slice) {
+  const size_t plane = (size_t)f.wl * f.h;
+  const int lane = threadIdx.x;
+  uint32_t item = 0;
+  if (lane == 0) {
+    const unsigned long long i = atomicAdd(&st.ctl[0], 1ull);
+    if (i >= st.cap) {
+      item = SLICE_EXIT; // more pops than entries: every push has its reader already
+    } else {
+      const uint32_t* entry = st.queue + i;
+      // An empty entry means the FIFO has run dry: the launch is in its last round and the groups still marching are held by
+      // other wavefronts.  Poll rarely (every few microseconds, backing off to ~50): thousands of idle wavefronts polling two
+      // addresses at full rate queue up on one memory channel, in front of the state traffic of the wavefronts still working.
+      for (int backoff = 1;; backoff = backoff < 16 ? backoff * 2 : 16) {
+        item = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (item != SLICE_EMPTY) break;
+        if (__hip_atomic_load(&st.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_groups) {
+          item = SLICE_EXIT;
+          break;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        for (int k = 0; k < backoff; k++) __builtin_amdgcn_s_sleep(127); // 127 x 64 cycles = 3.4 us
+      }
+    }
+  }
+  item = (uint32_t)__shfl((int)item, 0, 64);
+  if (item == SLICE_EXIT) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the group's state, written by the wavefront that pushed it
+  stage_dm_tables();
+#ifdef ATMRT_TIMELINE
+  const unsigned long long tl_slice_t0 = wall_clock64();
+#endif
+  unsigned long long steps = 0, lookups = 0;
+  const size_t p = (size_t)item * 64 + lane;
+  bool alive = false;
+  const int32_t i0 = p < plane ? st.step[p] : -1;
+  if (i0 >= 0) {
+    const Earth e = earth_for<CALC>(f);
+    Stepper s;
+    s.x = st.x[p];
+    s.a = st.a[p];
+    s.b = st.b[p];
+    s.hint = st.hint[p];
+    s.h0 = *f.alt;
+    s.ang = st.ang[p];
+    double sh = st.sh[p], path_length = st.pl[p], diff0 = st.diff0[p];
+    const DirCalc c = st.calc[p];
+    double re0 = sh, pl0 = path_length;
+    int first = -1;
+    alive = march_slice<CALC, CUBIC, false>(f, e, c, s, sh, path_length, diff0, re0, pl0, i0, slice, first, steps, lookups);
+    if (alive) {
+      st.x[p] = s.x;
+      st.a[p] = s.a;
+      st.b[p] = s.b;
+      st.hint[p] = s.hint;
+      st.sh[p] = sh;
+      st.pl[p] = path_length;
+      st.diff0[p] = diff0;
+      st.step[p] = i0 + slice;
+    } else {
+      st.step[p] = -1;
+      slice_finish<CALC>(out, hit_step, rec, p, first, re0, pl0, sh, path_length);
+    }
+  }
+  slice_requeue(st, item, alive);
+#ifdef ATMRT_TIMELINE
+  {
+    const int i0max = __reduce_max_sync_i0(i0);
+    const bool tl_again = __any(alive);
+    if (lane == 0) {
+      const unsigned long long k = atomicAdd(&g_slices[0], 1ull);
+      if (k < 262144) {
+        unsigned long long* r = g_slices + 8 + 4 * k;
+        r[0] = item | ((unsigned long long)(unsigned)i0max << 32);
+        r[1] = tl_slice_t0;
+        r[2] = wall_clock64();
+        r[3] = blockIdx.x | ((unsigned long long)(__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu) << 32) |
+               ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) << 48);
+      }
+      if (item < 32768 && !tl_again) g_timeline[3 * item + 2] = wall_clock64(); // the group's last slice ended
+    }
+  }
+#endif
+  steps = wave_sum(steps);
+  lookups = wave_sum(lookups);
+  if (lane == 0 && steps) {
+    atomicAdd(&counters[0], steps);
+    atomicAdd(&counters[10], lookups);
+  }
+}
+
+// every group must have finished: anything else is reported through counters[12] and fails the frame (atmrt_api.hip)
+static __global__ void k_slice_check(const unsigned long long* __restrict__ ctl, uint32_t n_groups, unsigned long long* __restrict__ counters) {
+  counters[12] = ctl[2] == n_groups ? 0ull : 1ull + (n_groups > ctl[2] ? n_groups - ctl[2] : ctl[2] - n_groups);
 }
 
 // TracePoint of a recorded crossing of pixel (x, y) at step s
@@ -560,11 +857,58 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
 // launchers
 // ---------------------------------------------------------------------------------------------
 
+// The sliced march of an opaque-terrain frame: slice 0 as an ordinary grid, one host round trip for the number of groups still
+// marching (it bounds the entries the later slices can push: the grid of the second kernel), then one wavefront per entry.
+// false: the frame is not sliced (march_slice_layout) and the caller launches k_rect_march.
+template <bool CUBIC>
+static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DensePlanes& out, const RectRec& rec, hipStream_t stream) {
+  SliceLayout L;
+  if (!ws.slice_state || !march_slice_layout(f, L)) return false;
+  const size_t n = (size_t)f.wl * f.h;
+  const int slice = MARCH_SLICE_STEPS;
+  SliceState st;
+  char* q = ws.slice_state;
+  st.calc = (DirCalc*)q; q += L.n_pad * sizeof(DirCalc);
+  st.x = (double*)q; q += L.n_pad * 8;
+  st.a = (double*)q; q += L.n_pad * 8;
+  st.b = (double*)q; q += L.n_pad * 8;
+  st.sh = (double*)q; q += L.n_pad * 8;
+  st.pl = (double*)q; q += L.n_pad * 8;
+  st.diff0 = (double*)q; q += L.n_pad * 8;
+  st.ang = (double*)q; q += L.n_pad * 8;
+  st.step = (int32_t*)q; q += L.n_pad * 4;
+  st.hint = (int32_t*)q; q += L.n_pad * 4;
+  st.ctl = (unsigned long long*)q; q += 64;
+  st.queue = (uint32_t*)q;
+  st.cap = (uint32_t)L.cap;
+  (void)hipMemsetAsync(st.ctl, 0, 64, stream);
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_first<CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
+                                                        ws.hit_step, rec, (unsigned long long*)ws.counters, st, L.n_groups, slice));
+  unsigned long long ctl_host[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(ctl_host, st.ctl, sizeof ctl_host, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return true; // the error is sticky: the caller's next HIP call reports it
+  // a group pushes at most once per slice it survives
+  const size_t entries = std::min<size_t>(L.cap, (size_t)ctl_host[1] * L.slices_after);
+  if (entries) {
+    (void)hipMemsetAsync(st.queue + ctl_host[1], 0xff, (entries - (size_t)ctl_host[1]) * sizeof(uint32_t), stream);
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_cont<CALC, CUBIC>), dim3((unsigned)entries), dim3(64), 0, stream, f,
+                                                          out, ws.hit_step, rec, (unsigned long long*)ws.counters, st, L.n_groups, slice));
+  }
+  hipLaunchKernelGGL(k_slice_check, dim3(1), dim3(1), 0, stream, (const unsigned long long*)st.ctl, L.n_groups,
+                     (unsigned long long*)ws.counters);
+  return true;
+}
+
 template <bool CUBIC>
 void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, n);
-  if (f.opaque) {
+  if (f.opaque && launch_rect_march_sliced<CUBIC>(f, ws, out, rec, stream)) {
+    (void)hipEventRecord(ev_marched, stream);
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
+                                                          f, ws.hit_step, rec, out));
+  } else if (f.opaque) {
     ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
                        (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
     (void)hipEventRecord(ev_marched, stream);

@@ -36,3 +36,15 @@ void launch_rect_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, cons
   else launch_rect_trace_fill_t<false>(f, ws, n_hits, dense, packed, stream);
 }
 } // namespace atmrt
+
+#ifdef ATMRT_TIMELINE
+extern "C" int atmrt_debug_timeline(unsigned long long* dst, size_t n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(atmrt::g_timeline), n_words * sizeof(unsigned long long));
+}
+extern "C" int atmrt_debug_slices(unsigned long long* dst, size_t n_words) {
+  int rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(atmrt::g_slices), n_words * sizeof(unsigned long long));
+  unsigned long long zero = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(atmrt::g_slices), &zero, sizeof zero);
+  return rc;
+}
+#endif

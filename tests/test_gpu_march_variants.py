@@ -1,8 +1,11 @@
-"""k_rect_march exists in two builds — the plain one (4 wavefronts per SIMD, no scratch: launches above 16384 workgroups, i.e. the
-headline frame) and the small-launch one (wave priorities that fall with progress, 5 wavefronts per SIMD: multi-GPU shards, test
-frames) — picked by the size of the launch (atmrt_march_impl.h, ATMRT_LAUNCH_MARCH).  Every test frame below 4 Mpixel runs the second
-one, so this test forces each variant in a child process (ATMRT_MARCH_VARIANT is read once per process) and requires the same bits
-from both for opaque, translucent and object scenes."""
+"""The Rectilinear march exists in three builds — the plain k_rect_march (4 wavefronts per SIMD, no scratch: launches above 16384
+workgroups, i.e. the headline frame), the small-launch one (wave priorities that fall with progress, 5 wavefronts per SIMD: shards
+and test frames with translucent terrain or objects) and, for small launches over opaque terrain, the time-sliced march
+(k_rect_march_first / _cont: ray state through HBM between slices of 128 steps, a FIFO of ray groups) — picked by the size and kind
+of the launch (atmrt_kernels.h march_slice_layout, atmrt_march_impl.h ATMRT_LAUNCH_MARCH).  Every test frame below 4 Mpixel runs the
+second or third, so this test forces each variant in a child process (ATMRT_MARCH_VARIANT is read once per process) and requires
+the same bits from all for opaque, translucent and object scenes; the opaque scene comes in a second size whose pixel count is not
+a multiple of a workgroup, and with a step that gives rays of 18 slices."""
 import hashlib
 import json
 import os
@@ -21,8 +24,9 @@ from atm_raytracer_amd import generators, synth
 from util import run_gpu, FIELDS_PIXEL, FIELDS_HIT, bits
 ctx = generators.Context(0)
 out = {{}}
-for name, kw, objects in (("opaque", dict(), False), ("translucent", dict(terrain_alpha=0.5), False), ("objects", dict(terrain_alpha=0.5), True)):
-    cfg, tiles = synth.scene("S2", 160, 96, generator="Rectilinear", max_distance=60_000.0, tilt=-1.0, **kw)
+for name, kw, objects, size in (("opaque", dict(), False, (160, 96)), ("translucent", dict(terrain_alpha=0.5), False, (160, 96)),
+                                ("objects", dict(terrain_alpha=0.5), True, (160, 96)), ("opaque-ragged", dict(step=26.0), False, (150, 61))):
+    cfg, tiles = synth.scene("S2", size[0], size[1], generator="Rectilinear", max_distance=60_000.0, tilt=-1.0, **kw)
     if objects:
         synth.add_objects(cfg, n_cyl=40, n_bill=10, dist=(300.0, 20_000.0), spread_deg=30.0, radius=(30.0, 120.0), height=(150.0, 600.0),
                           bill_w=(150.0, 500.0), bill_h=(150.0, 500.0))
@@ -49,7 +53,8 @@ def _run(variant):
 
 
 @pytest.mark.gpu
-def test_both_march_variants_produce_the_same_frames():
-    plain, small = _run("plain"), _run("small")
-    assert plain == small
+def test_all_march_variants_produce_the_same_frames():
+    plain, small, sliced, default = _run("plain"), _run("small"), _run("sliced"), _run(None)
+    assert plain == small == sliced == default
     assert plain["opaque"][1] > 1000 and plain["translucent"][1] > plain["opaque"][1] and plain["objects"][1] > 0
+    assert plain["opaque-ragged"][1] > 500

@@ -223,7 +223,7 @@ extern "C" void atmrt_ctx_destroy(atmrt_ctx* c) {
                     &c->d_list_step, &c->d_list_pixel, &c->d_rect_rec, &c->d_objects, &c->d_textures, &c->d_plat, &c->d_plon,
                     &c->d_ccount, &c->d_coffset, &c->d_clist, &c->d_px_steps, &c->d_atm, &c->d_interp, &c->d_lat_dense, &c->d_lat_packed,
                     &c->d_lat_offset, &c->d_dense, &c->d_packed, &c->d_io, &c->d_slot_step, &c->d_slot_rec, &c->d_overflow, &c->d_slot_pixel, &c->d_slot_packed, &c->d_pelev_t, &c->d_plen_t, &c->d_col_cand, &c->d_col_ncand, &c->d_path_seg, &c->d_dprev, &c->d_step_prop, &c->d_blend_arena,
-                    &c->d_object_rays, &c->d_slice})
+                    &c->d_object_rays, &c->d_slice, &c->d_overflow_arena})
     b->release(); // (a buffer missing from this list is released by its destructor when the context is deleted below)
   for (hipEvent_t ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -662,9 +662,17 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->list_pixel = nullptr;
   ws->step_prop = nullptr;
   ws->object_rays = nullptr;
+  ws->overflow_arena = nullptr;
+  ws->overflow_cap = 0;
+  ws->n_overflow_records = 0;
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR && !f.opaque && f.n_objects == 0) { // the counting march's crossings beyond the slots
+    ws->overflow_cap = std::max<size_t>(65536, npx / 4);
+    HIP_TRY(c, c->d_overflow_arena.reserve(overflow_arena_bytes(ws->overflow_cap)));
+    ws->overflow_arena = c->d_overflow_arena.as<char>();
+  }
   ws->slice_state = nullptr;
   SliceLayout slices;
-  if (f.n_objects == 0 && march_slice_layout(f, slices)) { // a small Rectilinear launch over opaque terrain: the time-sliced march
+  if (march_slice_layout(f, slices)) { // a small Rectilinear launch without scene objects: the time-sliced march
     HIP_TRY(c, c->d_slice.reserve(slices.bytes));
     ws->slice_state = c->d_slice.as<char>();
   }
@@ -785,7 +793,8 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
         ws.rect_rec = c->d_rect_rec.as<double>();
       }
       if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
-        ws.n_overflow = counters[3]; // pixels whose points did not fit the slots: the only ones marched a second time
+        ws.n_overflow = counters[3]; // pixels whose points did not fit the slots: marched a second time if the arena overflowed too
+        ws.n_overflow_records = counters[13];
         HIP_TRY(c, c->d_overflow.reserve((ws.n_overflow + 1) * sizeof(uint32_t)));
         ws.overflow = c->d_overflow.as<uint32_t>();
         HIP_TRY(c, hipMemsetAsync(ws.counters + 3, 0, sizeof(uint64_t), s)); // now the gather kernel's list cursor
@@ -1008,7 +1017,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->stats.unlisted_columns = counters[5];
   c->stats.big_steps = counters[6];
   c->stats.big_blend_pixels += counters[7];
-  c->stats.retraced_pixels += ws.n_overflow;
+  c->stats.retraced_pixels += ws.overflow_arena && ws.n_overflow_records <= ws.overflow_cap ? 0 : ws.n_overflow;
   c->stats.terrain_lookups = counters[10];
   c->stats.object_rays = counters[11];
   if (ms_out) *ms_out = ms;

@@ -85,11 +85,34 @@ struct PathSegState {
 // [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
 // together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march,
 // [11] rays of a scene with objects that the lean march left to the general tracer
-constexpr int N_COUNTERS = 13; // [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks)
+constexpr int N_COUNTERS = 14; // [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks); [13]: records appended to the overflow arena
 
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
 constexpr int RECT_SLOTS = 4;
+
+// Crossings of the counting march beyond a pixel's RECT_SLOTS slots (translucent terrain): appended in any order, each with its
+// pixel and its ordinal among the pixel's crossings; counters[13] = records appended (more than `cap`: the arena is not used and
+// the overflowing pixels are marched a second time, as before round 3).  44 B per record.
+struct OverflowArena {
+  uint32_t *pixel, *ordinal, *step;
+  double *re0, *pl0, *re1, *pl1;
+  uint32_t cap;
+};
+static inline size_t overflow_arena_bytes(size_t cap) { return cap * (3 * sizeof(uint32_t) + 4 * sizeof(double)); }
+static inline OverflowArena carve_overflow(char* base, size_t cap) {
+  OverflowArena a{};
+  if (!base) return a;
+  a.re0 = (double*)base;
+  a.pl0 = a.re0 + cap;
+  a.re1 = a.pl0 + cap;
+  a.pl1 = a.re1 + cap;
+  a.pixel = (uint32_t*)(a.pl1 + cap);
+  a.ordinal = a.pixel + cap;
+  a.step = a.ordinal + cap;
+  a.cap = (uint32_t)cap;
+  return a;
+}
 
 // The time-sliced march of small Rectilinear launches (atmrt_march_impl.h, k_rect_march_first / _cont): which launches take it and
 // what they need.  A launch of at most MARCH_SMALL_MAX_BLOCKS 256-thread blocks is "small" (a few resident sets: column shards of a
@@ -111,18 +134,18 @@ struct SliceLayout {
   size_t cap;            // FIFO entries: n_groups x slices_after
   size_t bytes;          // of Workspace::slice_state
 };
-// false: this frame's march is not sliced (not opaque-terrain-only, one slice long, too big, or forced otherwise)
+// false: this frame's march is not sliced (scene objects, rays one slice long, too big a launch, or forced otherwise)
 static inline bool march_slice_layout(const Frame& f, SliceLayout& L) {
   const size_t n = (size_t)f.wl * f.h;
   const int ov = march_variant_override();
-  if (f.p.generator != ATMRT_GEN_RECTILINEAR || !f.opaque || n == 0 || f.n_t + 2 <= MARCH_SLICE_STEPS) return false;
+  if (f.p.generator != ATMRT_GEN_RECTILINEAR || f.n_objects != 0 || n == 0 || f.n_t + 2 <= MARCH_SLICE_STEPS) return false;
   if (ov ? ov != 3 : (n + 255) / 256 > MARCH_SMALL_MAX_BLOCKS) return false;
   L.n_groups = (uint32_t)((n + 63) / 64);
   L.n_pad = (size_t)L.n_groups * 64;
   L.slices_after = ((size_t)f.n_t + 2 + MARCH_SLICE_STEPS - 1) / MARCH_SLICE_STEPS;
   L.cap = (size_t)L.n_groups * L.slices_after;
   if (L.cap > 0x7fffffffull) return false; // (a frame of > 2^31 slices is marched whole)
-  L.bytes = L.n_pad * (7 * sizeof(double) + 2 * sizeof(int32_t) + sizeof(DirCalc)) + 64 + L.cap * sizeof(uint32_t);
+  L.bytes = L.n_pad * (7 * sizeof(double) + 3 * sizeof(int32_t) + sizeof(DirCalc)) + 64 + L.cap * sizeof(uint32_t);
   return true;
 }
 
@@ -166,6 +189,9 @@ struct Workspace {
   uint32_t* object_rays;  // Rectilinear, scenes with objects: pixels the lean march left to the general tracer
   double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
+  char* overflow_arena;   // Rectilinear, translucent terrain: crossings beyond the slots (OverflowArena), or null
+  size_t overflow_cap;    // its capacity in records
+  uint64_t n_overflow_records; // host copy of counters[13] after the counting march
   char* slice_state;      // time-sliced march (march_slice_layout): ray state between two slices + the FIFO of groups, or null
 };
 

@@ -88,6 +88,21 @@ constexpr int DRAIN_PRIO_BAND = 512;
 #ifndef ATMRT_MARCH_WAVES_SMALL
 #define ATMRT_MARCH_WAVES_SMALL 5
 #endif
+// a crossing beyond the slots of its pixel: one record in the arena (0.7 % of the headline's pixels at terrain_alpha 0.5 have any)
+static __device__ __forceinline__ void overflow_append(const OverflowArena& ovf, unsigned long long* counters, uint32_t p, unsigned ordinal,
+                                                       uint32_t step, double re0, double pl0, double re1, double pl1) {
+  const unsigned long long k = atomicAdd(&counters[13], 1ull);
+  if (k < ovf.cap) {
+    ovf.pixel[k] = p;
+    ovf.ordinal[k] = ordinal;
+    ovf.step[k] = step;
+    ovf.re0[k] = re0;
+    ovf.pl0[k] = pl0;
+    ovf.re1[k] = re1;
+    ovf.pl1[k] = pl1;
+  }
+}
+
 #ifdef ATMRT_TIMELINE
 // Experiment hook (tools/measure_march_timeline.py; never defined in the product build): start / end time and steps of every
 // wavefront of the last k_rect_march launch, read back through atmrt_debug_timeline.
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
-                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list) {
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list, OverflowArena ovf) {
 #ifdef ATMRT_TIMELINE
   const unsigned long long tl_t0 = wall_clock64();
 #endif
@@ -243,6 +258,8 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
               rec.pl0[q] = pl0;
               rec.re1[q] = sh;
               rec.pl1[q] = path_length;
+            } else {
+              overflow_append(ovf, counters, (uint32_t)p, count, (uint32_t)(i - 1), re0, pl0, sh, path_length);
             }
           } else if (MODE == 2) {
             list_step[k] = (uint32_t)(i - 1);
@@ -312,27 +329,31 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
 }
 
 // ---------------------------------------------------------------------------------------------
-// Time-sliced march (opaque terrain, no objects) for launches of a few resident sets: column shards of a frame.
+// Time-sliced march (terrain only: MODE 0 opaque, MODE 1 translucent with the crossings counted into slots) for launches of a few
+// resident sets: the column tiles of a multi-GPU frame.
 //
-// Why.  A shard of the headline at 8 GPUs is 16384 wavefronts of which 7688 march all 2000 steps: 1.5 resident sets of 5120.  The
+// Why.  A tile of the headline at 8 GPUs is 16384 wavefronts of which 7688 march all 2000 steps: 1.5 resident sets of 5120.  The
 // hardware hands the second set to whichever CUs drain first (the wavefront timeline of such a launch, tools/
 // measure_march_timeline.py: 132 CUs take five more workgroups each, 124 take none and sit idle for the last 5 ms of 34), and no
-// order of the grid changes that.  Here the grid is PERSISTENT (one workgroup per resident slot) and a wavefront's unit of work is
-// a SLICE of a group of 64 rays: it takes the group's state from HBM, marches at most `slice` steps, puts the state back and
-// appends the group to the FIFO it took it from.  All groups thus advance together, the long ones end together in the last round
-// of slices, and the drain is one slice long instead of one ray long.  The state of a ray between two slices is 56 B (x, a, b,
-// the last sample's height, path length and ray-minus-terrain difference, step number, layer hint); direction, elevation and the
-// geodesic calculator are recomputed at the start of a slice (the same operations on the same inputs: the same bits).
+// order of the grid changes that.  So the unit of work is made smaller than a ray: a SLICE of a group of 64 consecutive pixels.
+// k_rect_march_first (an ordinary grid) marches the first `slice` steps of every ray and leaves, for the rays still marching, their
+// state in HBM and their group in a FIFO; k_rect_march_cont serves the FIFO with one single-wavefront workgroup per entry: read the
+// group's state, march `slice` steps, write it back, append the group again — or count it finished.  All groups advance together,
+// the long ones end in the same round, and the launch drains in one slice instead of one ray.
+// The state of a ray between two slices: x, a, b, the last sample's height, path length and ray-minus-terrain difference, the
+// elevation angle (straight rays), step number, layer hint, crossings so far (MODE 1) — 64 B — and, written once, its geodesic
+// calculator (128 B).
 //
-// Queue: `ctl[0]` = pops claimed, `ctl[1]` = pushes claimed, `ctl[2]` = groups finished.  Pop number i < n_groups is group i's first
-// slice (no memory read); pop number n_groups + t is the t-th push, awaited in queue[t] (one reader per entry, entries never
-// reused: capacity = groups x slices per ray).  A wavefront waiting for its entry leaves when every group has finished; a
-// wavefront holding a group never waits, so the grid drains whatever part of it is resident.
+// FIFO: ctl[0] = entries claimed by readers, ctl[1] = entries written, ctl[2] = groups finished.  Entries are never reused (capacity:
+// groups x slices a ray can need) and each has exactly one reader, the workgroup whose claim returned its index.  A reader whose
+// entry is still empty waits for it — the writer is a wavefront that is marching, never one that waits — and gives up when every
+// group has finished (its index is then beyond the last entry that will ever be written).
 struct SliceState {
   double *x, *a, *b, *sh, *pl, *diff0, *ang; // [plane]
   int32_t *step, *hint;                      // [plane]; step < 0: the ray has finished
+  uint32_t* count;                           // [plane] MODE 1: crossings so far
   DirCalc* calc;                             // [plane] the ray's geodesic calculator
-  uint32_t* queue;                           // [cap], 0xffffffff = not pushed yet
+  uint32_t* queue;                           // [cap], 0xffffffff = not written yet
   unsigned long long* ctl;                   // [4]
   uint32_t cap;
 };
@@ -341,9 +362,8 @@ constexpr uint32_t SLICE_EMPTY = 0xffffffffu, SLICE_EXIT = 0xfffffffeu;
 #define ATMRT_SLICE_WAVES 4 // per SIMD: 128 VGPRs, no scratch (5 per SIMD measured equal: the slices hide the drain the fifth wave was for)
 #endif
 
-
 #ifdef ATMRT_TIMELINE
-static __device__ __forceinline__ int __reduce_max_sync_i0(int v) {
+static __device__ __forceinline__ int timeline_wave_max(int v) {
   for (int o = 32; o; o >>= 1) {
     const int u = __shfl_xor(v, o, 64);
     v = u > v ? u : v;
@@ -351,11 +371,21 @@ static __device__ __forceinline__ int __reduce_max_sync_i0(int v) {
   return v;
 }
 #endif
+
+// What a slice leaves behind besides the state: MODE 0 the first crossing, MODE 1 the slots of the counting march (k_rect_march<1>)
+struct SliceSinks {
+  int32_t* hit_step;   // MODE 0
+  RectRec rec;         // MODE 0: [plane]; MODE 1: slot-major [RECT_SLOTS][plane]
+  uint32_t* slot_step; // MODE 1
+  OverflowArena ovf;   // MODE 1: crossings beyond the slots
+};
+
 // one slice of the march of a ray whose state is in registers; returns true when the ray is still marching after step i0 + slice
-template <int CALC, bool CUBIC, bool FAIR>
+template <int MODE, int CALC, bool CUBIC>
 static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& e, const DirCalc& c, Stepper& s, double& sh,
                                                    double& path_length, double& diff0, double& re0, double& pl0, int i0, int slice,
-                                                   int& first, unsigned long long& steps, unsigned long long& lookups) {
+                                                   int& first, unsigned& count, const SliceSinks& sinks, unsigned long long* counters, size_t p,
+                                                   size_t plane, unsigned long long& steps, unsigned long long& lookups) {
   const bool sph = e.spherical != 0;
   const double radius = e.shape_radius;
   const bool straight = f.p.straight_rays != 0;
@@ -363,19 +393,7 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
   const double skip_above = f.tv.skip_above;
   double sx = s.x, lat, lon;
   const int i_end = i0 + slice;
-  const int quarter = slice >> 2;
   for (int i = i0 + 1;; i++) {
-    if (FAIR) {
-      // The SIMD issues oldest-wavefront-first: left alone, the oldest persistent wavefront of a SIMD runs its slices at the speed of
-      // its dependency chain and the youngest gets what is left — nine times fewer slices, and the groups it holds fall rounds
-      // behind the others (they were the 4.5 ms tail of a 35 ms launch).  A slice therefore starts at priority 3 and gives way a
-      // level per quarter: whoever is behind within its slice runs first, the wavefronts of a SIMD take turns.
-      const int k = i - i0 - 1;
-      if (k == 0) __builtin_amdgcn_s_setprio(3);
-      else if (k == quarter) __builtin_amdgcn_s_setprio(2);
-      else if (k == 2 * quarter) __builtin_amdgcn_s_setprio(1);
-      else if (k == 3 * quarter) __builtin_amdgcn_s_setprio(0);
-    }
     bool tame;
     RayState nx = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
     if (straight) tame = __all(calc_dist_in_band(*f.atm, sh) && calc_dist_in_band(*f.atm, nx.h));
@@ -390,9 +408,22 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
       lookups++;
     }
     steps++;
-    if (diff0 * diff1 < 0.0) { // utils.rs:222; opaque terrain ends the march here (utils.rs:237-239)
-      first = i - 1;
-      return false;
+    if (diff0 * diff1 < 0.0) { // utils.rs:222
+      if (MODE == 0) { // opaque terrain ends the march here (utils.rs:237-239)
+        first = i - 1;
+        return false;
+      }
+      if (count < (unsigned)RECT_SLOTS) { // as k_rect_march<1>
+        const size_t q = (size_t)count * plane + p;
+        sinks.slot_step[q] = (uint32_t)(i - 1);
+        sinks.rec.re0[q] = re0;
+        sinks.rec.pl0[q] = pl0;
+        sinks.rec.re1[q] = sh;
+        sinks.rec.pl1[q] = path_length;
+      } else {
+        overflow_append(sinks.ovf, counters, (uint32_t)p, count, (uint32_t)(i - 1), re0, pl0, sh, path_length);
+      }
+      count++;
     }
     diff0 = diff1;
     re0 = sh;
@@ -401,17 +432,23 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
   }
 }
 
-template <int CALC>
-static __device__ __forceinline__ void slice_finish(const DensePlanes& out, int32_t* hit_step, const RectRec& rec, size_t p, int first,
-                                                    double re0, double pl0, double sh, double path_length) {
-  if (first >= 0) { // ray elevation and path length at the two samples that bracket the crossing
-    rec.re0[p] = re0;
-    rec.pl0[p] = pl0;
-    rec.re1[p] = sh;
-    rec.pl1[p] = path_length;
+// the ray has ended: its per-pixel results (azimuth and elevation angle were written by the first slice)
+template <int MODE>
+static __device__ __forceinline__ void slice_finish(const DensePlanes& out, const SliceSinks& sinks, unsigned long long* counters, size_t p,
+                                                    int first, unsigned count, double re0, double pl0, double sh, double path_length) {
+  if (MODE == 0) {
+    if (first >= 0) { // ray elevation and path length at the two samples that bracket the crossing
+      sinks.rec.re0[p] = re0;
+      sinks.rec.pl0[p] = pl0;
+      sinks.rec.re1[p] = sh;
+      sinks.rec.pl1[p] = path_length;
+    }
+    out.hit_count[p] = first >= 0 ? 1u : 0u;
+    sinks.hit_step[p] = first;
+  } else {
+    out.hit_count[p] = count;
+    if (count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
   }
-  out.hit_count[p] = first >= 0 ? 1u : 0u;
-  hit_step[p] = first;
 }
 
 // wave-uniform end of a group's slice: announce the group again, or count it as finished
@@ -429,10 +466,10 @@ static __device__ __forceinline__ void slice_requeue(const SliceState& st, uint3
 }
 
 // slice 0 of every group: an ordinary grid (it is short: the launch drains in a fraction of a slice)
-template <int CALC, bool CUBIC>
-__global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
-                                                                             RectRec rec, unsigned long long* __restrict__ counters,
-                                                                             SliceState st, uint32_t n_groups, int slice) {
+template <int MODE, int CALC, bool CUBIC>
+__global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Frame f, DensePlanes out, SliceSinks sinks,
+                                                                             unsigned long long* __restrict__ counters, SliceState st,
+                                                                             uint32_t n_groups, int slice) {
 #ifdef ATMRT_TIMELINE
   const unsigned long long tl_t0 = wall_clock64();
 #endif
@@ -454,13 +491,15 @@ __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Fra
     out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
     out.elevation_angle[p] = dm_to_degrees(elevation);
     int first = -1;
+    unsigned count = 0;
     double sh = alt, path_length = 0.0, re0 = alt, pl0 = 0.0, diff0 = 0.0;
     if (!(0.0 > f.p.frame.max_distance || alt < -1000.0)) { // the reference would panic on an empty stream
       double lat, lon;
       coords_at_dist(e, c, 0.0, lat, lon);
       diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
       lookups++;
-      alive = march_slice<CALC, CUBIC, false>(f, e, c, s, sh, path_length, diff0, re0, pl0, 0, slice, first, steps, lookups);
+      alive = march_slice<MODE, CALC, CUBIC>(f, e, c, s, sh, path_length, diff0, re0, pl0, 0, slice, first, count, sinks, counters, p, plane,
+                                             steps, lookups);
     }
     if (alive) {
       st.x[p] = s.x;
@@ -472,10 +511,11 @@ __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Fra
       st.pl[p] = path_length;
       st.diff0[p] = diff0;
       st.step[p] = slice;
+      if (MODE == 1) st.count[p] = count;
       st.calc[p] = c;
     } else {
       st.step[p] = -1;
-      slice_finish<CALC>(out, hit_step, rec, p, first, re0, pl0, sh, path_length);
+      slice_finish<MODE>(out, sinks, counters, p, first, count, re0, pl0, sh, path_length);
     }
   }
   if ((p >> 6) < n_groups) slice_requeue(st, (uint32_t)(p >> 6), alive); // (the last block may hold wavefronts past the last group)
@@ -497,19 +537,19 @@ __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Fra
 // the later slices: one single-wavefront workgroup per queue entry.  NOT a persistent grid: the SIMD issues oldest-wavefront-first,
 // and persistent wavefronts keep their age order for the whole launch — the oldest of a SIMD ran its slices at the speed of its
 // dependency chain (0.57 ms), the youngest in 5 ms (measured, tools/measure_slice_timeline.py), groups that met the slow ones fell
-// five rounds behind and were a 4.5 ms tail; s_setprio did not change that.  A wavefront that lives for one slice starts youngest
-// and ends oldest: every slice sees every rank and the groups stay in step.
-template <int CALC, bool CUBIC>
-__global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame f, DensePlanes out, int32_t* __restrict__ hit_step,
-                                                                           RectRec rec, unsigned long long* __restrict__ counters,
-                                                                           SliceState st, uint32_t n_groups, int slice) {
+// five rounds behind and were a 4.5 ms tail; s_setprio per quarter slice did not change that.  A wavefront that lives for one slice
+// starts youngest and ends oldest: every slice sees every rank and the groups stay in step.
+template <int MODE, int CALC, bool CUBIC>
+__global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame f, DensePlanes out, SliceSinks sinks,
+                                                                           unsigned long long* __restrict__ counters, SliceState st,
+                                                                           uint32_t n_groups, int slice) {
   const size_t plane = (size_t)f.wl * f.h;
   const int lane = threadIdx.x;
   uint32_t item = 0;
   if (lane == 0) {
     const unsigned long long i = atomicAdd(&st.ctl[0], 1ull);
     if (i >= st.cap) {
-      item = SLICE_EXIT; // more pops than entries: every push has its reader already
+      item = SLICE_EXIT; // more readers than entries: every entry has its reader already
     } else {
       const uint32_t* entry = st.queue + i;
       // An empty entry means the FIFO has run dry: the launch is in its last round and the groups still marching are held by
@@ -529,7 +569,9 @@ __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame
   }
   item = (uint32_t)__shfl((int)item, 0, 64);
   if (item == SLICE_EXIT) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the group's state, written by the wavefront that pushed it
+  // the group's state, written by the wavefront that announced it — on any XCD: agent scope it has to be (with workgroup-scope
+  // fences the step counts of a frame change: stale state out of another XCD's L2)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   stage_dm_tables();
 #ifdef ATMRT_TIMELINE
   const unsigned long long tl_slice_t0 = wall_clock64();
@@ -551,7 +593,9 @@ __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame
     const DirCalc c = st.calc[p];
     double re0 = sh, pl0 = path_length;
     int first = -1;
-    alive = march_slice<CALC, CUBIC, false>(f, e, c, s, sh, path_length, diff0, re0, pl0, i0, slice, first, steps, lookups);
+    unsigned count = MODE == 1 ? st.count[p] : 0u;
+    alive = march_slice<MODE, CALC, CUBIC>(f, e, c, s, sh, path_length, diff0, re0, pl0, i0, slice, first, count, sinks, counters, p, plane,
+                                           steps, lookups);
     if (alive) {
       st.x[p] = s.x;
       st.a[p] = s.a;
@@ -561,15 +605,16 @@ __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame
       st.pl[p] = path_length;
       st.diff0[p] = diff0;
       st.step[p] = i0 + slice;
+      if (MODE == 1) st.count[p] = count;
     } else {
       st.step[p] = -1;
-      slice_finish<CALC>(out, hit_step, rec, p, first, re0, pl0, sh, path_length);
+      slice_finish<MODE>(out, sinks, counters, p, first, count, re0, pl0, sh, path_length);
     }
   }
   slice_requeue(st, item, alive);
 #ifdef ATMRT_TIMELINE
   {
-    const int i0max = __reduce_max_sync_i0(i0);
+    const int i0max = timeline_wave_max(i0);
     const bool tl_again = __any(alive);
     if (lane == 0) {
       const unsigned long long k = atomicAdd(&g_slices[0], 1ull);
@@ -857,11 +902,11 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
 // launchers
 // ---------------------------------------------------------------------------------------------
 
-// The sliced march of an opaque-terrain frame: slice 0 as an ordinary grid, one host round trip for the number of groups still
-// marching (it bounds the entries the later slices can push: the grid of the second kernel), then one wavefront per entry.
+// The sliced march of a terrain-only frame: slice 0 as an ordinary grid, one host round trip for the number of groups still
+// marching (it bounds the entries the later slices can write: the grid of the second kernel), then one wavefront per entry.
 // false: the frame is not sliced (march_slice_layout) and the caller launches k_rect_march.
-template <bool CUBIC>
-static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DensePlanes& out, const RectRec& rec, hipStream_t stream) {
+template <int MODE, bool CUBIC>
+static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DensePlanes& out, const SliceSinks& sinks, hipStream_t stream) {
   SliceLayout L;
   if (!ws.slice_state || !march_slice_layout(f, L)) return false;
   const size_t n = (size_t)f.wl * f.h;
@@ -878,22 +923,23 @@ static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DenseP
   st.ang = (double*)q; q += L.n_pad * 8;
   st.step = (int32_t*)q; q += L.n_pad * 4;
   st.hint = (int32_t*)q; q += L.n_pad * 4;
+  st.count = (uint32_t*)q; q += L.n_pad * 4;
   st.ctl = (unsigned long long*)q; q += 64;
   st.queue = (uint32_t*)q;
   st.cap = (uint32_t)L.cap;
   (void)hipMemsetAsync(st.ctl, 0, 64, stream);
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_first<CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f, out,
-                                                        ws.hit_step, rec, (unsigned long long*)ws.counters, st, L.n_groups, slice));
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_first<MODE, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f,
+                                                        out, sinks, (unsigned long long*)ws.counters, st, L.n_groups, slice));
   unsigned long long ctl_host[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(ctl_host, st.ctl, sizeof ctl_host, hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize(stream) != hipSuccess)
     return true; // the error is sticky: the caller's next HIP call reports it
-  // a group pushes at most once per slice it survives
+  // a group writes at most one entry per slice it survives
   const size_t entries = std::min<size_t>(L.cap, (size_t)ctl_host[1] * L.slices_after);
   if (entries) {
     (void)hipMemsetAsync(st.queue + ctl_host[1], 0xff, (entries - (size_t)ctl_host[1]) * sizeof(uint32_t), stream);
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_cont<CALC, CUBIC>), dim3((unsigned)entries), dim3(64), 0, stream, f,
-                                                          out, ws.hit_step, rec, (unsigned long long*)ws.counters, st, L.n_groups, slice));
+    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_cont<MODE, CALC, CUBIC>), dim3((unsigned)entries), dim3(64), 0, stream,
+                                                          f, out, sinks, (unsigned long long*)ws.counters, st, L.n_groups, slice));
   }
   hipLaunchKernelGGL(k_slice_check, dim3(1), dim3(1), 0, stream, (const unsigned long long*)st.ctl, L.n_groups,
                      (unsigned long long*)ws.counters);
@@ -904,20 +950,21 @@ template <bool CUBIC>
 void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, n);
-  if (f.opaque && launch_rect_march_sliced<CUBIC>(f, ws, out, rec, stream)) {
-    (void)hipEventRecord(ev_marched, stream);
-    ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
-                                                          f, ws.hit_step, rec, out));
-  } else if (f.opaque) {
-    ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                       (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
+  if (f.opaque) {
+    if (!launch_rect_march_sliced<0, CUBIC>(f, ws, out, SliceSinks{ws.hit_step, rec, nullptr, OverflowArena{}}, stream)) {
+      ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{});
+    }
     (void)hipEventRecord(ev_marched, stream);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
                                                           f, ws.hit_step, rec, out));
   } else {
     RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
-    ATMRT_LAUNCH_MARCH(1, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, (uint32_t*)nullptr,
-                       (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
+    const OverflowArena ovf = carve_overflow(ws.overflow_arena, ws.overflow_cap);
+    if (!launch_rect_march_sliced<1, CUBIC>(f, ws, out, SliceSinks{nullptr, slots, ws.slot_step, ovf}, stream)) {
+      ATMRT_LAUNCH_MARCH(1, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, (uint32_t*)nullptr,
+                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, ovf);
+    }
     (void)hipEventRecord(ev_marched, stream);
   }
 }
@@ -929,12 +976,17 @@ static __global__ __launch_bounds__(256) void k_rect_gather_slots(Frame f, const
                                                            const uint32_t* __restrict__ slot_step, RectRec slots,
                                                            uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                            RectRec rec, uint32_t* __restrict__ overflow,
-                                                           unsigned long long* __restrict__ counters) {
+                                                           unsigned long long* __restrict__ counters, int arena) {
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = p < plane ? hit_count[p] : 0u;
-  wave_compact_append(n > (uint32_t)RECT_SLOTS, (uint32_t)p, overflow, &counters[3]); // the pixels the second march visits
-  if (p >= plane || n > (uint32_t)RECT_SLOTS) return;
+  uint32_t n = p < plane ? hit_count[p] : 0u;
+  if (arena) { // the crossings beyond the slots are in the overflow arena (k_rect_scatter_overflow): the slots of every pixel count
+    n = n < (uint32_t)RECT_SLOTS ? n : (uint32_t)RECT_SLOTS;
+  } else {
+    wave_compact_append(n > (uint32_t)RECT_SLOTS, (uint32_t)p, overflow, &counters[3]); // the pixels the second march visits
+    if (n > (uint32_t)RECT_SLOTS) return;
+  }
+  if (p >= plane) return;
   const uint64_t k = hit_offset[p];
   for (uint32_t j = 0; j < n; j++) {
     const size_t q = (size_t)j * plane + p;
@@ -947,6 +999,23 @@ static __global__ __launch_bounds__(256) void k_rect_gather_slots(Frame f, const
   }
 }
 
+// the arena's records to their places in the pixel-ordered list: crossing number `ordinal` of pixel p is entry hit_offset[p] + ordinal
+static __global__ __launch_bounds__(256) void k_rect_scatter_overflow(uint32_t n_records, OverflowArena ovf,
+                                                                      const uint64_t* __restrict__ hit_offset,
+                                                                      uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                                      RectRec rec) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_records) return;
+  const uint32_t p = ovf.pixel[r];
+  const uint64_t k = hit_offset[p] + ovf.ordinal[r];
+  list_step[k] = ovf.step[r];
+  list_pixel[k] = p;
+  rec.re0[k] = ovf.re0[r];
+  rec.pl0[k] = ovf.pl0[r];
+  rec.re1[k] = ovf.re1[r];
+  rec.pl1[k] = ovf.pl1[r];
+}
+
 // terrain_alpha < 1, Rectilinear: gather the recorded crossings, march the overflow pixels again listing every crossing,
 // then one thread per trace point
 template <bool CUBIC>
@@ -955,11 +1024,19 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
+  // the crossings beyond the slots: out of the overflow arena when all of them fitted it — a second march of those pixels otherwise
+  // (0.7 % of the headline's pixels: a launch of one wavefront per SIMD, 12.8 ms at any frame or tile size, and most of the fill)
+  const bool arena = ws.overflow_arena && ws.n_overflow_records <= ws.overflow_cap;
   hipLaunchKernelGGL(k_rect_gather_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count, ws.hit_offset,
-                     ws.slot_step, slots, ws.list_step, ws.list_pixel, rec, ws.overflow, (unsigned long long*)ws.counters);
-  if (ws.n_overflow) {
+                     ws.slot_step, slots, ws.list_step, ws.list_pixel, rec, ws.overflow, (unsigned long long*)ws.counters, arena ? 1 : 0);
+  if (arena) {
+    if (ws.n_overflow_records)
+      hipLaunchKernelGGL(k_rect_scatter_overflow, dim3(cdiv((size_t)ws.n_overflow_records, 256)), dim3(256), 0, stream,
+                         (uint32_t)ws.n_overflow_records, carve_overflow(ws.overflow_arena, ws.overflow_cap), ws.hit_offset, ws.list_step,
+                         ws.list_pixel, rec);
+  } else if (ws.n_overflow) {
     ATMRT_LAUNCH_MARCH(2, ws.n_overflow, stream, f, dense, ws.hit_step, ws.hit_offset, rec, ws.list_step, ws.list_pixel,
-                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow);
+                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow, OverflowArena{});
   }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
@@ -984,7 +1061,7 @@ void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes&
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
   ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
-                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u);
+                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{});
   hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
                      (unsigned long long*)ws.counters);
 }

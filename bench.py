@@ -347,6 +347,11 @@ def main():
                        "frac": rate / FP64_ISSUE_PEAK, "issue_slot_frac": rate / FP64_ISSUE_PEAK, "traffic": traffic, "valu": valu, "hbm": hbm}
         elif "sq_stale" in cached:
             out["valu"] = {"stale": cached["sq_stale"]}
+        if kernel == "k_rect_march" and args.objects == 0 and args.terrain_alpha == 1.0 and (wl * H + 255) // 256 <= 16384:
+            # a launch of at most 16384 workgroups over opaque terrain (a column tile of a multi-GPU frame) runs the time-sliced
+            # march; march_ms covers both of its kernels and the host round trip between them
+            out["kernel_variant"] = ("time-sliced: k_rect_march_first + k_rect_march_cont (profiles/r03/shard_march_profile_8.json); "
+                                     "the cached counters are k_rect_march's — the same loop without the slice state")
         out.update({"kernel": kernel, "kernel_ms": ms, "terrain_samples_per_launch": lookups if kernel == "k_rect_march" else None,
                     "phase_ms": {k: mean(k) for k in phase[0] if k.endswith("_ms")},
                     "all_kernels": {per_kernel[k][0]: kernel_entry(k) for k in keys if mean(k) > 0}})

@@ -2,7 +2,7 @@
 """Load balance of the pixel-column tiles of the headline frame: every one of the G shards a G-GPU run would compute is timed on
 ONE GPU (one after the other, best of five back-to-back runs).  mean / max of the shard times is the load balance; the sum of the
 shard times against the G = 1 time is what splitting costs the march itself (tail of a smaller grid); both bound the strong-scaling
-efficiency from above (the all-gather comes on top).   python tools/measure_shard_balance.py [G ...]"""
+efficiency from above (the all-gather comes on top).   python tools/measure_shard_balance.py [G ...] [alpha=0.5]"""
 import json
 import os
 import sys
@@ -13,11 +13,12 @@ import torch  # noqa: E402
 from atm_raytracer_amd import generators, sharding, synth  # noqa: E402
 
 W, H = 4096, 2048
-cfg, tiles = synth.scene("headline", W, H, generator="Rectilinear", level=2)
+ALPHA = [float(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("alpha=")]  # alpha=0.5: translucent terrain (the counting march)
+cfg, tiles = synth.scene("headline", W, H, generator="Rectilinear", level=2, **(dict(terrain_alpha=ALPHA[0]) if ALPHA else {}))
 ctx = generators.Context(0)
 terrain = generators.Terrain.from_tiles(tiles, ctx)
 out = {}
-for G in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+for G in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8]:
     times, steps = [], []
     for g in range(G):
         c0, c1 = sharding.column_shard(W, g, G)

@@ -665,10 +665,13 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->overflow_arena = nullptr;
   ws->overflow_cap = 0;
   ws->n_overflow_records = 0;
-  if (f.p.generator == ATMRT_GEN_RECTILINEAR && !f.opaque && f.n_objects == 0) { // the counting march's crossings beyond the slots
+  ws->overflow_packed = PackedHits{};
+  if (f.p.generator == ATMRT_GEN_RECTILINEAR && !f.opaque) { // the counting passes' trace points beyond the slots
     ws->overflow_cap = std::max<size_t>(65536, npx / 4);
-    HIP_TRY(c, c->d_overflow_arena.reserve(overflow_arena_bytes(ws->overflow_cap)));
+    const size_t rec_bytes = (overflow_arena_bytes(ws->overflow_cap) + 255) / 256 * 256;
+    HIP_TRY(c, c->d_overflow_arena.reserve(rec_bytes + (f.n_objects ? packed_bytes(ws->overflow_cap) : 0)));
     ws->overflow_arena = c->d_overflow_arena.as<char>();
+    if (f.n_objects) ws->overflow_packed = carve_packed(ws->overflow_arena + rec_bytes, ws->overflow_cap);
   }
   ws->slice_state = nullptr;
   SliceLayout slices;
@@ -1017,7 +1020,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->stats.unlisted_columns = counters[5];
   c->stats.big_steps = counters[6];
   c->stats.big_blend_pixels += counters[7];
-  c->stats.retraced_pixels += ws.overflow_arena && ws.n_overflow_records <= ws.overflow_cap ? 0 : ws.n_overflow;
+  c->stats.retraced_pixels += ws.n_overflow;
   c->stats.terrain_lookups = counters[10];
   c->stats.object_rays = counters[11];
   if (ms_out) *ms_out = ms;

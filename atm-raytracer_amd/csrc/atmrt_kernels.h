@@ -91,12 +91,17 @@ constexpr int N_COUNTERS = 14; // [12]: groups the time-sliced march left unfini
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
 constexpr int RECT_SLOTS = 4;
 
-// Crossings of the counting march beyond a pixel's RECT_SLOTS slots (translucent terrain): appended in any order, each with its
-// pixel and its ordinal among the pixel's crossings; counters[13] = records appended (more than `cap`: the arena is not used and
-// the overflowing pixels are marched a second time, as before round 3).  44 B per record.
+// Trace points beyond a pixel's RECT_SLOTS slots (translucent terrain, scenes with objects): appended by the counting passes in any
+// order, each with its pixel and its ordinal among the pixel's trace points; counters[13] = records appended (more than `cap`: the
+// arena is not used and the overflowing pixels are marched / traced a second time, as before round 3).  44 B per record, + a
+// PackedHits entry (100 B) in scenes with objects, where a record is a complete object point or a terrain record with its tag.
+// `lean_source`: set in the records of the lean march of an object scene — those of a ray the march later hands to the general
+// tracer (hit_step[p] = 1 there) are void, the tracer appends that ray's points itself.
+constexpr uint32_t OVERFLOW_LEAN = 0x80000000u;
 struct OverflowArena {
   uint32_t *pixel, *ordinal, *step;
   double *re0, *pl0, *re1, *pl1;
+  uint32_t* color_tag; // scenes with objects: the PackedHits arena's tags (the lean march writes TERRAIN), else null
   uint32_t cap;
 };
 static inline size_t overflow_arena_bytes(size_t cap) { return cap * (3 * sizeof(uint32_t) + 4 * sizeof(double)); }
@@ -110,6 +115,7 @@ static inline OverflowArena carve_overflow(char* base, size_t cap) {
   a.pixel = (uint32_t*)(a.pl1 + cap);
   a.ordinal = a.pixel + cap;
   a.step = a.ordinal + cap;
+  a.color_tag = nullptr;
   a.cap = (uint32_t)cap;
   return a;
 }
@@ -189,7 +195,8 @@ struct Workspace {
   uint32_t* object_rays;  // Rectilinear, scenes with objects: pixels the lean march left to the general tracer
   double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
-  char* overflow_arena;   // Rectilinear, translucent terrain: crossings beyond the slots (OverflowArena), or null
+  char* overflow_arena;   // Rectilinear, translucent terrain or objects: trace points beyond the slots (OverflowArena), or null
+  PackedHits overflow_packed; // scenes with objects: the arena's complete points
   size_t overflow_cap;    // its capacity in records
   uint64_t n_overflow_records; // host copy of counters[13] after the counting march
   char* slice_state;      // time-sliced march (march_slice_layout): ray state between two slices + the FIFO of groups, or null

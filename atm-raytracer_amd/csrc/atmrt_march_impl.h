@@ -91,15 +91,17 @@ constexpr int DRAIN_PRIO_BAND = 512;
 // a crossing beyond the slots of its pixel: one record in the arena (0.7 % of the headline's pixels at terrain_alpha 0.5 have any)
 static __device__ __forceinline__ void overflow_append(const OverflowArena& ovf, unsigned long long* counters, uint32_t p, unsigned ordinal,
                                                        uint32_t step, double re0, double pl0, double re1, double pl1) {
+  if (!ovf.cap) return;
   const unsigned long long k = atomicAdd(&counters[13], 1ull);
   if (k < ovf.cap) {
     ovf.pixel[k] = p;
-    ovf.ordinal[k] = ordinal;
+    ovf.ordinal[k] = ovf.color_tag ? ordinal | OVERFLOW_LEAN : ordinal;
     ovf.step[k] = step;
     ovf.re0[k] = re0;
     ovf.pl0[k] = pl0;
     ovf.re1[k] = re1;
     ovf.pl1[k] = pl1;
+    if (ovf.color_tag) ovf.color_tag[k] = ATMRT_COLOR_TERRAIN;
   }
 }
 
@@ -278,6 +280,8 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
               rec.pl0[q] = pl0;
               rec.re1[q] = sh;
               rec.pl1[q] = path_length;
+            } else {
+              overflow_append(ovf, counters, (uint32_t)p, count, (uint32_t)(i - 1), re0, pl0, sh, path_length);
             }
           }
           count++;
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
         rec.pl1[p] = path_length;
       }
     }
+    if (MODE == 3) hit_step[p] = object_ray ? 1 : 0; // voids the ray's overflow records (k_rect_scatter_trace_overflow)
     if (MODE == 3 && object_ray) { // nothing of this ray counts: k_rect_trace starts it again
       out.hit_count[p] = OBJECT_RAY;
       steps = 0;
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
                                                     uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
                                                     const uint32_t* __restrict__ pixel_list, uint32_t n_list,
-                                                    double* __restrict__ step_prop) {
+                                                    double* __restrict__ step_prop, OverflowArena ovf, PackedHits ovf_packed) {
   // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
   // (packed / rec / list_step then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its place in
   // the pixel-ordered list, for all pixels or for the listed ones (those that did not fit their slots).
@@ -876,6 +881,21 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
             rec.pl0[q] = pl0;
             rec.re1[q] = sh_;
             rec.pl1[q] = path_length;
+          }
+        }
+        else if (!FILL && hits.n && hits.n <= STEP_CANDIDATES && ovf.cap) { // beyond the slots: the step's points into the overflow arena
+          const unsigned long long base = atomicAdd(&counters[13], (unsigned long long)hits.n);
+          if (base + (unsigned long long)hits.n <= ovf.cap) {
+            uint64_t kk = base;
+            step_emit(hits, ovf_packed, ovf.step, ovf.pixel, kk, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx,
+                      path_length);
+            for (uint64_t q = base; q < kk; q++) {
+              ovf.ordinal[q] = count + (unsigned)(q - base);
+              ovf.re0[q] = re0;
+              ovf.pl0[q] = pl0;
+              ovf.re1[q] = sh_;
+              ovf.pl1[q] = path_length;
+            }
           }
         }
         count += (unsigned)hits.n;
@@ -1053,6 +1073,12 @@ static __global__ __launch_bounds__(256) void k_collect_object_rays(size_t n, co
   wave_compact_append(p < n && hit_count[p] == OBJECT_RAY, (uint32_t)p, list, &counters[11]); // the rays the general tracer visits
 }
 
+// the overflow arena of a scene with objects: records + complete points
+static inline OverflowArena trace_overflow_arena(const Workspace& ws) {
+  OverflowArena a = carve_overflow(ws.overflow_arena, ws.overflow_cap);
+  if (a.cap) a.color_tag = ws.overflow_packed.color_tag;
+  return a;
+}
 // Scenes with objects, counting pass, phase 1: the lean march over every pixel (terrain crossings into the tracer's slot arena,
 // rays that can meet an object flagged and listed); phase 2 (launch_rect_trace_objects_t, after the host has read the list's
 // length) traces the listed rays with the general tracer.
@@ -1061,7 +1087,7 @@ void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes&
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
   ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
-                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{});
+                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws));
   hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
                      (unsigned long long*)ws.counters);
 }
@@ -1073,7 +1099,8 @@ void launch_rect_trace_objects_t(const Frame& f, Workspace& ws, const DensePlane
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv((size_t)n_rays, 256)), dim3(256), 0, stream, f, out,
                                                         (const uint64_t*)nullptr, ws.slot_packed, slots, ws.slot_step,
                                                         ws.slot_pixel, (unsigned long long*)ws.counters,
-                                                        (const uint32_t*)ws.object_rays, (uint32_t)n_rays, (double*)nullptr));
+                                                        (const uint32_t*)ws.object_rays, (uint32_t)n_rays, (double*)nullptr,
+                                                        trace_overflow_arena(ws), ws.overflow_packed));
 }
 
 // Trace points kept in the slot arena by the counting pass of k_rect_trace, moved to their places in the pixel-ordered list
@@ -1084,12 +1111,19 @@ static __global__ __launch_bounds__(256) void k_rect_gather_trace_slots(Frame f,
                                                                         PackedHits sp, uint32_t* __restrict__ list_step,
                                                                         uint32_t* __restrict__ list_pixel, RectRec rec,
                                                                         PackedHits packed, uint32_t* __restrict__ overflow,
-                                                                        unsigned long long* __restrict__ counters) {
+                                                                        unsigned long long* __restrict__ counters, int arena) {
   const size_t plane = (size_t)f.wl * f.h;
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = p < plane ? hit_count[p] : 0u;
-  wave_compact_append(n > (uint32_t)RECT_SLOTS, (uint32_t)p, overflow, &counters[3]); // the pixels the tracer's fill pass visits
-  if (p >= plane || n > (uint32_t)RECT_SLOTS) return;
+  uint32_t n = p < plane ? hit_count[p] : 0u;
+  if (arena) {
+    // the points beyond the slots are in the overflow arena: the slots of every pixel count.  (A pixel's last slots may be stale —
+    // a step whose points did not all fit went to the arena whole — k_rect_scatter_trace_overflow, which runs next, overwrites them.)
+    n = n < (uint32_t)RECT_SLOTS ? n : (uint32_t)RECT_SLOTS;
+  } else {
+    wave_compact_append(n > (uint32_t)RECT_SLOTS, (uint32_t)p, overflow, &counters[3]); // the pixels the tracer's fill pass visits
+    if (n > (uint32_t)RECT_SLOTS) return;
+  }
+  if (p >= plane) return;
   const uint64_t k0 = hit_offset[p];
   for (uint32_t j = 0; j < n; j++) {
     const size_t q = p * RECT_SLOTS + j;
@@ -1114,20 +1148,63 @@ static __global__ __launch_bounds__(256) void k_rect_gather_trace_slots(Frame f,
   }
 }
 
+// the arena's records to their places in the pixel-ordered list (scenes with objects)
+static __global__ __launch_bounds__(256) void k_rect_scatter_trace_overflow(uint32_t n_records, OverflowArena ovf, PackedHits ap,
+                                                                            const int32_t* __restrict__ handed_over,
+                                                                            const uint64_t* __restrict__ hit_offset,
+                                                                            uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
+                                                                            RectRec rec, PackedHits packed) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_records) return;
+  const uint32_t p = ovf.pixel[r];
+  uint32_t ordinal = ovf.ordinal[r];
+  if (ordinal & OVERFLOW_LEAN) { // a record of the lean march: void if the ray went to the tracer afterwards
+    if (handed_over[p]) return;
+    ordinal &= ~OVERFLOW_LEAN;
+  }
+  const uint64_t k = hit_offset[p] + ordinal;
+  list_step[k] = ovf.step[r];
+  list_pixel[k] = p;
+  rec.re0[k] = ovf.re0[r];
+  rec.pl0[k] = ovf.pl0[r];
+  rec.re1[k] = ovf.re1[r];
+  rec.pl1[k] = ovf.pl1[r];
+  const uint32_t tag = ap.color_tag[r];
+  packed.color_tag[k] = tag;
+  if (tag != ATMRT_COLOR_TERRAIN) { // terrain points are completed by k_rect_finalize_list
+    packed.lat[k] = ap.lat[r];
+    packed.lon[k] = ap.lon[r];
+    packed.distance[k] = ap.distance[r];
+    packed.elevation[k] = ap.elevation[r];
+    packed.path_length[k] = ap.path_length[r];
+    for (int c = 0; c < 3; c++) packed.normal[3 * k + c] = ap.normal[3 * r + c];
+    for (int c = 0; c < 4; c++) packed.rgba[4 * k + c] = ap.rgba[4 * r + c];
+  }
+}
+
 template <bool CUBIC>
 void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                               hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, (size_t)n_hits);
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
+  // the points beyond the slots: out of the overflow arena — unless it overflowed itself or a step had more points than the
+  // in-register step list (those are sorted in HBM by the fill pass): then the general tracer visits those pixels a second time
+  // (config 5: 22.7 ms for 1.3 % of the pixels — one wavefront per SIMD, at the speed of its dependency chain)
+  const bool arena = ws.overflow_arena && ws.n_overflow_records <= ws.overflow_cap && !ws.step_prop;
   hipLaunchKernelGGL(k_rect_gather_trace_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count,
                      ws.hit_offset, ws.slot_step, slots, ws.slot_packed, ws.list_step, ws.list_pixel, rec, packed, ws.overflow,
-                     (unsigned long long*)ws.counters);
-  if (ws.n_overflow) {
+                     (unsigned long long*)ws.counters, arena ? 1 : 0);
+  if (arena) {
+    if (ws.n_overflow_records)
+      hipLaunchKernelGGL(k_rect_scatter_trace_overflow, dim3(cdiv((size_t)ws.n_overflow_records, 256)), dim3(256), 0, stream,
+                         (uint32_t)ws.n_overflow_records, trace_overflow_arena(ws), ws.overflow_packed, (const int32_t*)ws.hit_step,
+                         ws.hit_offset, ws.list_step, ws.list_pixel, rec, packed);
+  } else if (ws.n_overflow) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<true, CALC, CUBIC>), dim3(cdiv((size_t)ws.n_overflow, 256)), dim3(256), 0,
                                                           stream, f, dense, ws.hit_offset, packed, rec, ws.list_step, ws.list_pixel,
                                                           (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow,
-                                                          (uint32_t)ws.n_overflow, ws.step_prop));
+                                                          (uint32_t)ws.n_overflow, ws.step_prop, OverflowArena{}, PackedHits{}));
   }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,

@@ -277,7 +277,9 @@ typedef struct atmrt_frame_stats {
   uint64_t unlisted_rays;     /* Rectilinear, scenes with objects: rays with more candidate objects than the per-ray list
                                  holds (24) — they test every object at every sample (is_close, frustum.rs:103-114) */
   uint64_t unlisted_columns;  /* Fast / InterpolatingRectilinear: columns with more candidates than the per-column list (64) */
-  uint64_t retraced_pixels;   /* Rectilinear: pixels with more trace points than the 4 slots of the counting march, marched again */
+  uint64_t retraced_pixels;   /* Rectilinear: pixels with more trace points than the 4 slots of the counting pass: their further
+                                 points come out of an overflow arena (marched / traced a second time only when the arena is full or
+                                 big_steps > 0) */
   uint64_t big_steps;         /* steps that produced more trace points than the in-register step list (12): sorted in HBM */
   uint64_t big_blend_pixels;  /* InterpolatingRectilinear: pixels whose four lattice corners hold more than 4 trace points together
                                  (blended over a member arena in HBM; any number of points) */

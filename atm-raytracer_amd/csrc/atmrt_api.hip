@@ -667,7 +667,11 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->n_overflow_records = 0;
   ws->overflow_packed = PackedHits{};
   if (f.p.generator == ATMRT_GEN_RECTILINEAR && !f.opaque) { // the counting passes' trace points beyond the slots
-    ws->overflow_cap = std::max<size_t>(65536, npx / 4);
+    static const long forced_cap = [] { // test hook: a tiny arena forces the second-pass route (tests/test_gpu_march_variants.py)
+      const char* e = getenv("ATMRT_OVERFLOW_CAP");
+      return e ? atol(e) : -1L;
+    }();
+    ws->overflow_cap = forced_cap >= 0 ? (size_t)forced_cap : std::max<size_t>(65536, npx / 4);
     const size_t rec_bytes = (overflow_arena_bytes(ws->overflow_cap) + 255) / 256 * 256;
     HIP_TRY(c, c->d_overflow_arena.reserve(rec_bytes + (f.n_objects ? packed_bytes(ws->overflow_cap) : 0)));
     ws->overflow_arena = c->d_overflow_arena.as<char>();

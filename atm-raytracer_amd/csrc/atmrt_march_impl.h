@@ -1046,7 +1046,7 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
   // the crossings beyond the slots: out of the overflow arena when all of them fitted it — a second march of those pixels otherwise
   // (0.7 % of the headline's pixels: a launch of one wavefront per SIMD, 12.8 ms at any frame or tile size, and most of the fill)
-  const bool arena = ws.overflow_arena && ws.n_overflow_records <= ws.overflow_cap;
+  const bool arena = ws.overflow_arena && ws.overflow_cap && ws.n_overflow_records <= ws.overflow_cap;
   hipLaunchKernelGGL(k_rect_gather_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count, ws.hit_offset,
                      ws.slot_step, slots, ws.list_step, ws.list_pixel, rec, ws.overflow, (unsigned long long*)ws.counters, arena ? 1 : 0);
   if (arena) {
@@ -1191,7 +1191,7 @@ void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, co
   // the points beyond the slots: out of the overflow arena — unless it overflowed itself or a step had more points than the
   // in-register step list (those are sorted in HBM by the fill pass): then the general tracer visits those pixels a second time
   // (config 5: 22.7 ms for 1.3 % of the pixels — one wavefront per SIMD, at the speed of its dependency chain)
-  const bool arena = ws.overflow_arena && ws.n_overflow_records <= ws.overflow_cap && !ws.step_prop;
+  const bool arena = ws.overflow_arena && ws.overflow_cap && ws.n_overflow_records <= ws.overflow_cap && !ws.step_prop;
   hipLaunchKernelGGL(k_rect_gather_trace_slots, dim3(cdiv(n, 256)), dim3(256), 0, stream, f, (const uint32_t*)dense.hit_count,
                      ws.hit_offset, ws.slot_step, slots, ws.slot_packed, ws.list_step, ws.list_pixel, rec, packed, ws.overflow,
                      (unsigned long long*)ws.counters, arena ? 1 : 0);

@@ -21,7 +21,7 @@ import hashlib, json, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
 import numpy as np
 from atm_raytracer_amd import generators, synth
-from util import run_gpu, FIELDS_PIXEL, FIELDS_HIT, bits
+from util import run_gpu, FIELDS_PIXEL, FIELDS_HIT, bits, frame_stats
 ctx = generators.Context(0)
 out = {{}}
 for name, kw, objects, size in (("opaque", dict(), False, (160, 96)), ("translucent", dict(terrain_alpha=0.5), False, (160, 96)),
@@ -34,13 +34,13 @@ for name, kw, objects, size in (("opaque", dict(), False, (160, 96)), ("transluc
     h = hashlib.sha256()
     for k in FIELDS_PIXEL + FIELDS_HIT:
         h.update(np.ascontiguousarray(bits(r[k])).tobytes())
-    out[name] = [h.hexdigest(), int(r["n_hits"]), int(r["ray_steps"])]
+    out[name] = [h.hexdigest(), int(r["n_hits"]), int(r["ray_steps"]), int(frame_stats(ctx)["retraced_pixels"])]
 print("RESULT " + json.dumps(out))
 """
 
 
-def _run(variant):
-    env = dict(os.environ)
+def _run(variant, **extra):
+    env = dict(os.environ, **extra)
     if variant:
         env["ATMRT_MARCH_VARIANT"] = variant
     else:
@@ -58,3 +58,7 @@ def test_all_march_variants_produce_the_same_frames():
     assert plain == small == sliced == default
     assert plain["opaque"][1] > 1000 and plain["translucent"][1] > plain["opaque"][1] and plain["objects"][1] > 0
     assert plain["opaque-ragged"][1] > 500
+    # Trace points beyond a pixel's four slots travel through the overflow arena; with an arena of 4 records (or none) they come
+    # from a second pass over those pixels instead — the route of rounds 1-2, still the fall-back.  Same bits.
+    assert plain["translucent"][3] > 4 and plain["objects"][3] > 4, "the scenes must have pixels beyond the slots"
+    assert _run(None, ATMRT_OVERFLOW_CAP="4") == plain and _run("sliced", ATMRT_OVERFLOW_CAP="0") == plain

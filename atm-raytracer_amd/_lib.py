@@ -91,6 +91,7 @@ def load():
         "atmrt_last_timings": (C.c_int, [vp, C.POINTER(_abi.Timings)]),
         "atmrt_last_stats": (C.c_int, [vp, C.POINTER(_abi.FrameStats)]),
         "atmrt_debug_fail_next_frame": (C.c_int, [vp]),
+        "atmrt_debug_march_plan": (C.c_int, [i32, i32, i32, i32, C.POINTER(C.c_uint64)]),
         "atmrt_coloring_from_conf": (C.c_int, [C.POINTER(_abi.Params), i32, dbl, dbl, dbl, dbl, i32, i32, dbl, C.POINTER(_abi.Coloring)]),
         "atmrt_draw_image": (C.c_int, [vp, C.POINTER(_abi.Coloring), vp]),
         "atmrt_draw_image_device": (C.c_int, [vp, C.POINTER(_abi.Coloring), vp]),
@@ -125,7 +126,7 @@ def load():
 EXPORTED = ["atmrt_abi_version", "atmrt_build_info", "atmrt_ctx_create", "atmrt_ctx_destroy", "atmrt_last_error", "atmrt_terrain_load_dir",
             "atmrt_terrain_add_tile", "atmrt_terrain_clear", "atmrt_terrain_get_elev", "atmrt_params_default",
             "atmrt_atmosphere_us76", "atmrt_set_params", "atmrt_set_atmosphere", "atmrt_objects_set", "atmrt_generate",
-            "atmrt_result_free", "atmrt_generate_device", "atmrt_last_hits_device", "atmrt_last_timings", "atmrt_last_stats", "atmrt_debug_fail_next_frame", "atmrt_coloring_from_conf", "atmrt_draw_image",
+            "atmrt_result_free", "atmrt_generate_device", "atmrt_last_hits_device", "atmrt_last_timings", "atmrt_last_stats", "atmrt_debug_fail_next_frame", "atmrt_debug_march_plan", "atmrt_coloring_from_conf", "atmrt_draw_image",
             "atmrt_draw_image_device", "atmrt_ray_paths", "atmrt_atmosphere_sample",
             "atmrt_coords_at_dist", "atmrt_math_probe", "atmrt_result_encode_bincode",
             "atmrt_result_decode_bincode", "atmrt_comm_unique_id", "atmrt_ctx_comm_init_rank", "atmrt_ctx_comm_init_external", "atmrt_ctx_comm_init_external_device",

@@ -1278,6 +1278,25 @@ extern "C" int atmrt_debug_fail_next_frame(atmrt_ctx* c) {
   return ATMRT_OK;
 }
 
+extern "C" int atmrt_debug_march_plan(int32_t width, int32_t height, int32_t samples, int32_t n_objects, uint64_t out[6]) {
+  if (!out || width < 0 || height < 0 || samples < 0 || n_objects < 0) return ATMRT_ERR_INVALID_ARGUMENT;
+  Frame f{};
+  f.p.generator = ATMRT_GEN_RECTILINEAR;
+  f.wl = width;
+  f.h = height;
+  f.n_t = samples;
+  f.n_objects = n_objects;
+  SliceLayout L{};
+  const bool sliced = march_slice_layout(f, L);
+  out[0] = sliced ? 1 : 0;
+  out[1] = sliced ? L.n_groups : 0;
+  out[2] = sliced ? L.cap : 0;
+  out[3] = sliced ? L.bytes : 0;
+  out[4] = sliced ? L.slices_after : 0;
+  out[5] = MARCH_SLICE_STEPS;
+  return ATMRT_OK;
+}
+
 extern "C" int atmrt_last_stats(atmrt_ctx* c, atmrt_frame_stats_t* out) {
   if (!c || !out) return ATMRT_ERR_INVALID_ARGUMENT;
   if (c->multi) return multi_last_stats(c, out);

@@ -295,6 +295,11 @@ int atmrt_last_stats(atmrt_ctx* ctx, atmrt_frame_stats_t* out);
  * fails with ATMRT_ERR_HIP (once).  After ANY failed frame atmrt_draw_image* and atmrt_last_hits_device return ATMRT_ERR_STATE
  * until a frame succeeds: the failed frame has already reused the buffers of the one before it. */
 int atmrt_debug_fail_next_frame(atmrt_ctx* ctx);
+/* How the Rectilinear march of a frame (or column tile) of width x height pixels with `samples` terrain samples per ray
+ * (ceil(max_distance / simulation_step)) is planned; no device needed.  out[0] = 1 when the time-sliced march is used (tiles of at
+ * most 4 Mpixel without scene objects), out[1] = ray groups, out[2] = the FIFO's capacity in entries, out[3] = bytes
+ * of slice state, out[4] = the bound on the slices a ray can need after the first, out[5] = steps per slice. */
+int atmrt_debug_march_plan(int32_t width, int32_t height, int32_t samples, int32_t n_objects, uint64_t out[6]);
 
 /* ---- renderer compositing + colouring on the device (src/renderer/mod.rs:367-414, src/coloring) -- */
 typedef enum atmrt_coloring_kind { ATMRT_COLORING_SIMPLE = 0, ATMRT_COLORING_SHADING = 1 } atmrt_coloring_kind;

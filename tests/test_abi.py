@@ -68,3 +68,29 @@ def test_no_cpu_fallback(lib):
     from atm_raytracer_amd import generators
     with pytest.raises(_lib.AtmrtError):
         generators.Context(0)
+
+
+def test_march_plan_of_frames_and_tiles(lib):
+    """Host logic of the time-sliced march (csrc/atmrt_kernels.h march_slice_layout): which launches take it and the sizes it reserves.
+    The FIFO must hold one entry per group and slice a ray can survive; the grid bound of its second kernel (alive groups x
+    slices) relies on `slices_after` covering every step count the march can reach (samples + 1 steps, the first slice excluded)."""
+    out = (C.c_uint64 * 6)()
+
+    def plan(w, h, samples, objects=0):
+        assert lib.atmrt_debug_march_plan(w, h, samples, objects, out) == 0
+        return list(out)
+
+    slice_steps = plan(8, 8, 10)[5]
+    assert slice_steps == 128
+    assert plan(4096, 2048, 2000)[0] == 0, "the whole headline frame (32768 workgroups) marches unsliced"
+    sliced, groups, cap, nbytes, after, _ = plan(512, 2048, 2000)  # a column tile of 8 GPUs
+    assert sliced == 1 and groups == 512 * 2048 // 64
+    assert after * slice_steps >= 2000 + 2 and (after - 1) * slice_steps < 2000 + 2 + slice_steps
+    assert cap == groups * after
+    assert nbytes == 512 * 2048 * (7 * 8 + 3 * 4 + 128) + 64 + 4 * cap
+    assert plan(2048, 2048, 2000)[0] == 1 and plan(2049, 2048, 2000)[0] == 0  # 16384 workgroups of 256 pixels is the limit
+    assert plan(512, 2048, 2000, objects=3)[0] == 0, "scenes with objects keep the lean march + tracer"
+    assert plan(64, 64, slice_steps - 2)[0] == 0 and plan(64, 64, slice_steps - 1)[0] == 1  # rays of one slice are not sliced
+    ragged = plan(150, 61, 2308)
+    assert ragged[1] == (150 * 61 + 63) // 64 and ragged[3] == ragged[1] * 64 * 196 + 64 + 4 * ragged[2]
+    assert lib.atmrt_debug_march_plan(-1, 1, 1, 0, out) != 0

@@ -1,5 +1,7 @@
+"""Phase times (library HIP events) of the translucent-terrain headline as a whole frame and as one tile of eight:
+   python tools/measure_phase_ms.py   (march_ms, pack_ms: the fill passes after the counting march)"""
 import sys, json
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from atm_raytracer_amd import generators, sharding, synth
 W, H = 4096, 2048

@@ -2,7 +2,7 @@
 """Load balance of the pixel-column tiles of the headline frame: every one of the G shards a G-GPU run would compute is timed on
 ONE GPU (one after the other, best of five back-to-back runs).  mean / max of the shard times is the load balance; the sum of the
 shard times against the G = 1 time is what splitting costs the march itself (tail of a smaller grid); both bound the strong-scaling
-efficiency from above (the all-gather comes on top).   python tools/measure_shard_balance.py [G ...] [alpha=0.5]"""
+efficiency from above (the all-gather comes on top).   python tools/measure_shard_balance.py [G ...] [alpha=0.5] [objects=1000]"""
 import json
 import os
 import sys
@@ -14,7 +14,10 @@ from atm_raytracer_amd import generators, sharding, synth  # noqa: E402
 
 W, H = 4096, 2048
 ALPHA = [float(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("alpha=")]  # alpha=0.5: translucent terrain (the counting march)
+OBJECTS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("objects=")]  # objects=1000 alpha=0.5: BASELINE config 5
 cfg, tiles = synth.scene("headline", W, H, generator="Rectilinear", level=2, **(dict(terrain_alpha=ALPHA[0]) if ALPHA else {}))
+if OBJECTS:
+    synth.add_objects(cfg, n_cyl=int(OBJECTS[0] * 0.7), n_bill=OBJECTS[0] - int(OBJECTS[0] * 0.7))
 ctx = generators.Context(0)
 terrain = generators.Terrain.from_tiles(tiles, ctx)
 out = {}

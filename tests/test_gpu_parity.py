@@ -680,3 +680,30 @@ def test_more_trace_points_in_one_step_than_the_step_list(gpu_ctx, oracle_det, g
     got = run_gpu(gpu_ctx, cfg, tiles)
     assert frame_stats(gpu_ctx)["big_steps"] > 0
     assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.5], ids=["opaque", "translucent"])
+@pytest.mark.parametrize("case", ["all-down", "all-up", "one-step-past-a-slice", "exactly-one-slice", "ragged-groups"])
+def test_time_sliced_march_edges(gpu_ctx, oracle_det, case, alpha):
+    """Corner cases of the time-sliced Rectilinear march (csrc/atmrt_march_impl.h, k_rect_march_first / _cont; every test frame of
+    more than 128 steps per ray takes it): every ray ends inside the first slice (no FIFO entry is ever written, the second kernel is
+    not launched), no ray ends before the last slice, rays of 129 steps (one step in the second slice) and of 128 (not sliced at
+    all: the plain kernel, for comparison of the boundary), and a frame whose pixel count is neither a multiple of a wavefront nor
+    of a workgroup."""
+    kw = dict(generator="Rectilinear", terrain_alpha=alpha)
+    if case == "all-down":
+        cfg, tiles = synth.scene("S2", 48, 20, tilt=-70.0, fov=30.0, max_distance=60_000.0, **kw)
+    elif case == "all-up":
+        cfg, tiles = synth.scene("S2", 48, 20, tilt=45.0, fov=30.0, max_distance=40_000.0, **kw)
+    elif case == "one-step-past-a-slice":
+        cfg, tiles = synth.scene("S2", 40, 24, tilt=-1.0, max_distance=12_850.0, **kw)  # 129 samples of 100 m
+    elif case == "exactly-one-slice":
+        cfg, tiles = synth.scene("S2", 40, 24, tilt=-1.0, max_distance=12_550.0, **kw)  # 126 samples: n_t + 2 = 128, unsliced
+    else:
+        cfg, tiles = synth.scene("S2", 37, 11, tilt=-2.0, max_distance=50_000.0, **kw)
+    got = run_gpu(gpu_ctx, cfg, tiles)
+    assert_bitexact(got, run_oracle(oracle_det, cfg, tiles))
+    if case == "all-down":
+        assert (got["hit_count"] > 0).all()
+    if case == "all-up":
+        assert got["n_hits"] == 0

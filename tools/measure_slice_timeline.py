@@ -32,18 +32,17 @@ base = int(first[:, 0].min())
 f0 = (first[:, 0].astype(np.int64) - base) / 1e5
 print(f"shard {g}/{G}: event {ms:.2f} ms; first-slice kernel: waves {len(first)}, start {f0.min():.2f}..{f0.max():.2f}")
 fin = first[:, 2].astype(np.int64)
-served = np.zeros(len(first), dtype=np.int64)
 fin_ms = np.where(fin > 10**9, (fin - base) / 1e5, np.nan)  # groups that ended in the first-slice kernel keep their step count there
 wl = c1 - c0
 late = np.argsort(-np.nan_to_num(fin_ms))[:40]
-print("  groups that finished last: (group, row, finish ms, slices served)")
+print("  groups that finished last: (group, row, finish ms)")
 for gidx in late[:40:3]:
-    print(f"    {gidx:6d} row {gidx * 64 // wl:5d} {fin_ms[gidx]:7.2f} {served[gidx]:3d}")
+    print(f"    {gidx:6d} row {gidx * 64 // wl:5d} {fin_ms[gidx]:7.2f}")
 rows = np.arange(len(fin_ms)) * 64 // wl
 for lo in range(0, H, 64):
     m = (rows >= lo) & (rows < lo + 64) & np.isfinite(fin_ms)
     if m.any():
-        print(f"    rows {lo:4d}-{lo + 63:4d}: groups {m.sum():4d} finish {np.nanmin(fin_ms[m]):6.2f}..{np.nanmax(fin_ms[m]):6.2f} slices {served[m].min()}..{served[m].max()}")
+        print(f"    rows {lo:4d}-{lo + 63:4d}: groups {m.sum():4d} finish {np.nanmin(fin_ms[m]):6.2f}..{np.nanmax(fin_ms[m]):6.2f}")
 
 assert lib.atmrt_debug_slices(sl.ctypes.data, sl.size) == 0
 ns = int(sl[0]); print("slices logged", ns)

@@ -112,12 +112,17 @@ def load():
         "atmrt_image_hits_device": (C.c_int, [vp, C.POINTER(_abi.DeviceHits), C.POINTER(C.c_uint64)]),
         "atmrt_draw_image_gathered_device": (C.c_int, [vp, C.POINTER(_abi.Coloring), C.POINTER(vp)]),
         "atmrt_last_comm_timings": (C.c_int, [vp, C.POINTER(_abi.CommTimings)]),
+        "atmrt_comm_available": (C.c_int, []),
+        "atmrt_ctx_tile_columns": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),
+        "atmrt_tiles_rebalance": (C.c_int, [i32, i32, C.POINTER(i32), pd, C.POINTER(i32)]),
+        "atmrt_debug_set_tiling": (C.c_int, [vp, C.POINTER(i32), i32]),
+        "atmrt_debug_fail_next_collective": (C.c_int, [vp, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if L.atmrt_abi_version() != 4:
+    if L.atmrt_abi_version() != 5:
         raise ImportError("libatmrt.so ABI version mismatch")
     _lib = L
     return L
@@ -131,4 +136,5 @@ EXPORTED = ["atmrt_abi_version", "atmrt_build_info", "atmrt_ctx_create", "atmrt_
             "atmrt_coords_at_dist", "atmrt_math_probe", "atmrt_result_encode_bincode",
             "atmrt_result_decode_bincode", "atmrt_comm_unique_id", "atmrt_ctx_comm_init_rank", "atmrt_ctx_comm_init_external", "atmrt_ctx_comm_init_external_device",
             "atmrt_ctx_create_multi", "atmrt_ctx_device_count", "atmrt_generate_image_device", "atmrt_image_hits_device",
-            "atmrt_draw_image_gathered_device", "atmrt_last_comm_timings"]
+            "atmrt_draw_image_gathered_device", "atmrt_last_comm_timings", "atmrt_comm_available", "atmrt_ctx_tile_columns",
+            "atmrt_tiles_rebalance", "atmrt_debug_set_tiling", "atmrt_debug_fail_next_collective"]

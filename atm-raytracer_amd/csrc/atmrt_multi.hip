@@ -25,6 +25,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <thread>
@@ -46,6 +47,7 @@ struct Rccl {
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr; // optional: only the watchdog of the probe collective uses it
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string error;
 };
@@ -74,6 +76,7 @@ Rccl* rccl() {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
       dlclose(r.handle);
       r.handle = nullptr;
@@ -118,6 +121,20 @@ size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
 // ---------------------------------------------------------------------------------------------
 namespace atmrt {
 
+// What every rank appends to its slab: the one collective of a frame also tells every rank how many trace points each tile holds
+// (so the lists need no exchange of totals — and no rank can disagree about whether a second collective happens), which frame the
+// slab belongs to (ranks out of step are an error, not a silently mixed image) and how long the tile took (the next frame's tiling).
+struct SlabTrailer {
+  uint64_t n_hits;  // trace points of the tile's packed lists (0 for a first-hit frame)
+  uint64_t seq;     // frames this rank has exchanged before this one
+  double tile_ms;   // device time of the tile's generate
+  uint32_t packed;  // 1: the frame has lists
+  uint32_t c0, c1;  // the tile's columns as this rank sees them
+  uint32_t _pad;
+};
+static_assert(sizeof(SlabTrailer) == 40, "the trailer travels as bytes");
+constexpr size_t SLAB_TRAILER_BYTES = 256; // its own 256-byte line at the end of the slab
+
 struct Comm {
   int rank = 0, world = 1;
   int route = ATMRT_ROUTE_NONE;
@@ -127,14 +144,26 @@ struct Comm {
   atmrt_all_gather_device_fn ext_dev = nullptr;
   void* ext_user = nullptr;
   hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr, ev_a1 = nullptr;
-  DevBuf d_slab, d_gathered, d_small, d_hits_send, d_hits_recv, d_loc_off, d_scan_tmp, d_rgb_tile, d_rgb_all;
+  DevBuf d_slab, d_gathered, d_small, d_hits_send, d_hits_recv, d_loc_off, d_scan_tmp, d_rgb_tile, d_rgb_all, d_tiling;
   HostBuf h_send, h_recv, h_stage;
+  // The pixel-column tiles.  `cols` (world + 1 boundaries) is the tiling the NEXT frame will use: equal widths to begin with
+  // (shard_begin), then — tile_rebalance — widths that equalise the tiles' times, computed by every rank from the same gathered
+  // trailers and therefore identical on all of them.  `cols_frame` is the tiling of the last frame that was exchanged (what the
+  // assembly kernels and the lists read; a copy lives in d_tiling).
+  std::vector<int> cols, cols_frame;
+  int cols_W = -1;
+  bool balance = false;      // re-tile after a frame whose slowest tile took more than 1 % longer than the mean
+  bool cols_pinned = false;  // atmrt_debug_set_tiling: the caller's tiling stays
   // geometry of the last frame
   int W = 0, H = 0, wl_max = 0;
   size_t slab_bytes = 0;
   DensePlanes slab_planes{};
   DensePlanes last_image{}; // where the last frame's [H][W] planes were assembled (caller-owned)
   bool image_valid = false;
+  bool exchanged = false;   // the last frame went through its collective on this rank (and so, by construction, on every rank)
+  uint64_t seq = 0;         // frames exchanged so far
+  std::vector<SlabTrailer> trailers; // of the last exchanged frame, one per rank
+  int fail_countdown = 0;   // atmrt_debug_fail_next_collective: the n-th collective from now fails on this rank
   atmrt_comm_timings_t tm{};
   // host-consumer route: this device's row totals and staging layout
   std::vector<uint64_t> row_total;
@@ -160,6 +189,7 @@ struct MultiGroup {
   std::vector<ncclComm_t> nccl;
   atmrt_comm_timings_t tm{};
 
+  std::string demoted;  // why the context left the RCCL route for peer copies (empty: it did not)
   bool aborted = false; // a device failed inside a task that has barriers: the others stop waiting (guarded by bm)
 
   // All devices meet here; false: one of them failed since the task began, and nobody waits any more.
@@ -225,10 +255,46 @@ struct MultiGroup {
   }
 };
 
+// The tiling the next frame of a `width`-column image uses: equal widths whenever the width (or nothing yet) says so.
+static void comm_tiling(Comm* cm, int width) {
+  const int G = cm->world;
+  if (cm->cols_W == width && (int)cm->cols.size() == G + 1) return;
+  cm->cols.resize((size_t)G + 1);
+  for (int g = 0; g <= G; g++) cm->cols[(size_t)g] = shard_begin(width, g, G);
+  cm->cols_W = width;
+  cm->cols_pinned = false;
+}
+
 void comm_columns(const atmrt_ctx* c, int width, int* c0, int* c1) {
   if (!c->comm) return;
-  *c0 = shard_begin(width, c->comm->rank, c->comm->world);
-  *c1 = shard_begin(width, c->comm->rank + 1, c->comm->world);
+  comm_tiling(c->comm, width);
+  *c0 = c->comm->cols[(size_t)c->comm->rank];
+  *c1 = c->comm->cols[(size_t)c->comm->rank + 1];
+}
+
+// Tile boundaries that would have equalised the tiles' times, had the cost per column been constant inside each tile: the inverse
+// of the piecewise-linear cumulative cost at k / G of its total.  A pure function of its arguments — every rank evaluates it on
+// the same gathered numbers and gets the same tiling.  Widths stay >= 1.  Returns false (and copies the input) when a time is
+// not a positive finite number.
+bool tiles_rebalance(int W, int G, const int* cols, const double* ms, int* out) {
+  for (int g = 0; g <= G; g++) out[g] = cols[g];
+  double total = 0.0;
+  for (int g = 0; g < G; g++) {
+    if (!(ms[g] > 0.0) || !(ms[g] < 1e300) || cols[g + 1] <= cols[g]) return false;
+    total += ms[g];
+  }
+  if (cols[0] != 0 || cols[G] != W) return false;
+  int g = 0;
+  double before = 0.0; // cost of the tiles left of tile g
+  for (int k = 1; k < G; k++) {
+    const double want = total * (double)k / (double)G;
+    while (g < G - 1 && before + ms[g] < want) before += ms[g], g++;
+    const double x = (double)cols[g] + (want - before) / ms[g] * (double)(cols[g + 1] - cols[g]);
+    out[k] = (int)(x + 0.5);
+  }
+  for (int k = 1; k < G; k++) out[k] = std::max(out[k], out[k - 1] + 1);
+  for (int k = G - 1; k >= 1; k--) out[k] = std::min(out[k], out[k + 1] - 1);
+  return true;
 }
 
 int multi_size(const atmrt_ctx* parent) { return parent->multi ? (int)parent->multi->kids.size() : 1; }
@@ -253,24 +319,28 @@ int multi_forward(atmrt_ctx* parent, const std::function<int(atmrt_ctx*)>& fn) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ int tile_begin(int width, int g, int world) { return (int)((long long)g * width / world); }
-__device__ __forceinline__ int tile_of_column(int x, int width, int world) {
-  int g = (int)((long long)x * world / width); // tile_begin(g) <= x always; it may be one tile short
-  while (g + 1 < world && tile_begin(width, g + 1, world) <= x) g++;
-  return g;
+// the tile of column x: the last g with cols[g] <= x (cols: world + 1 ascending boundaries, cols[0] = 0, cols[world] = W)
+__device__ __forceinline__ int tile_of_column(int x, const int* __restrict__ cols, int world) {
+  int lo = 0, hi = world;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cols[mid] <= x) lo = mid;
+    else hi = mid;
+  }
+  return lo;
 }
 
 // gathered: [G] slabs of `slab_bytes`; the slab of tile g is exactly what the generators write for a tile of H x wl_g pixels: 10 f64
 // planes [H][wl_g] back to back (the planar normal is the last three) and the u32 hit_count plane.  One thread per image pixel,
 // lanes = adjacent columns: reads and writes are coalesced inside a tile.
 __global__ __launch_bounds__(256) void k_assemble_image(const char* __restrict__ gathered, size_t slab_bytes, int W, int H, int G,
-                                                         DensePlanes image) {
+                                                         const int* __restrict__ cols, DensePlanes image) {
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t npx = (size_t)W * H;
   if (p >= npx) return;
   const int y = (int)(p / (size_t)W), x = (int)(p % (size_t)W);
-  const int g = tile_of_column(x, W, G);
-  const int c0 = tile_begin(W, g, G), wl = tile_begin(W, g + 1, G) - c0;
+  const int g = tile_of_column(x, cols, G);
+  const int c0 = cols[g], wl = cols[g + 1] - c0;
   const size_t si = (size_t)y * wl + (size_t)(x - c0), plane_stride = (size_t)H * wl;
   const double* src = reinterpret_cast<const double*>(gathered + (size_t)g * slab_bytes);
   image.azimuth[p] = src[0 * plane_stride + si];
@@ -287,12 +357,12 @@ __global__ __launch_bounds__(256) void k_assemble_image(const char* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_assemble_rgb(const uint8_t* __restrict__ gathered, size_t tile_bytes, int W, int H, int G,
-                                                       uint8_t* __restrict__ rgb) {
+                                                       const int* __restrict__ cols, uint8_t* __restrict__ rgb) {
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= (size_t)W * H) return;
   const int y = (int)(p / (size_t)W), x = (int)(p % (size_t)W);
-  const int g = tile_of_column(x, W, G);
-  const int c0 = tile_begin(W, g, G), wl = tile_begin(W, g + 1, G) - c0;
+  const int g = tile_of_column(x, cols, G);
+  const int c0 = cols[g], wl = cols[g + 1] - c0;
   const uint8_t* s = gathered + (size_t)g * tile_bytes + 3 * ((size_t)y * wl + (size_t)(x - c0));
   rgb[3 * p + 0] = s[0];
   rgb[3 * p + 1] = s[1];
@@ -309,15 +379,15 @@ struct HitBlock {
 // One thread per image pixel: its trace points move from its rank's block (at the rank's own offsets) to the image's offsets.
 __global__ __launch_bounds__(256) void k_gather_hits(const char* __restrict__ blocks, size_t block_bytes, size_t n_cap,
                                                       const uint64_t* __restrict__ loc_off, size_t off_stride, int W, int H, int G,
-                                                      const uint32_t* __restrict__ hit_count, const uint64_t* __restrict__ img_off,
-                                                      PackedHits out) {
+                                                      const int* __restrict__ cols, const uint32_t* __restrict__ hit_count,
+                                                      const uint64_t* __restrict__ img_off, PackedHits out) {
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= (size_t)W * H) return;
   const uint32_t cnt = hit_count[p];
   if (!cnt) return;
   const int y = (int)(p / (size_t)W), x = (int)(p % (size_t)W);
-  const int g = tile_of_column(x, W, G);
-  const int c0 = tile_begin(W, g, G), wl = tile_begin(W, g + 1, G) - c0;
+  const int g = tile_of_column(x, cols, G);
+  const int c0 = cols[g], wl = cols[g + 1] - c0;
   const uint64_t s0 = loc_off[(size_t)g * off_stride + (size_t)y * wl + (size_t)(x - c0)];
   const uint64_t d0 = img_off[p];
   const char* blk = blocks + (size_t)g * block_bytes;
@@ -353,10 +423,26 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
     if (r_ != ncclSuccess) return (ctx)->fail(ATMRT_ERR_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(r_)); \
   } while (0)
 
+// A group context (several devices of ONE process) on the RCCL route: every device's host thread passes here before it enqueues
+// its part of a collective.  (1) Nothing that may allocate or map device memory runs on one thread while another device of the
+// process already sits inside the collective's kernel waiting for it — hipMalloc with peer access enabled may wait for the peers.
+// (2) A device that has failed (or where a failure was injected) releases the others here instead of leaving them inside
+// ncclAllGather, which has no way out.  The peer-copy route has its own two barriers.
+static int group_gate(atmrt_ctx* c) {
+  Comm* cm = c->comm;
+  if (!cm->group || cm->world == 1) return ATMRT_OK;
+  if (!cm->group->barrier()) return c->fail(ATMRT_ERR_STATE, "another device of the context failed during this frame");
+  return ATMRT_OK;
+}
+
 // Every rank's `bytes` at `send` -> all of them, rank-major, at `recv` (both in this rank's HBM), ordered on c->stream.
 int comm_all_gather(atmrt_ctx* c, const void* send, void* recv, size_t bytes) {
   Comm* cm = c->comm;
   hipStream_t s = c->stream;
+  if (cm && cm->fail_countdown > 0 && --cm->fail_countdown == 0) { // atmrt_debug_fail_next_collective
+    if (cm->group) cm->group->abort_task();
+    return c->fail(ATMRT_ERR_HIP, "collective failure injected by atmrt_debug_fail_next_collective (rank %d)", cm->rank);
+  }
   if (!cm || (cm->world == 1 && cm->route != ATMRT_ROUTE_EXTERNAL && cm->route != ATMRT_ROUTE_EXTERNAL_DEVICE)) {
     if (cm && cm->nccl) { // RCCL at world size 1: the same call as with 8 ranks
       NCCL_TRY(c, rccl()->AllGather(send, recv, bytes, ncclUint8, cm->nccl, s));
@@ -366,9 +452,16 @@ int comm_all_gather(atmrt_ctx* c, const void* send, void* recv, size_t bytes) {
     return ATMRT_OK;
   }
   switch (cm->route) {
-    case ATMRT_ROUTE_RCCL:
-      NCCL_TRY(c, rccl()->AllGather(send, recv, bytes, ncclUint8, cm->nccl, s));
+    case ATMRT_ROUTE_RCCL: {
+      int rc = group_gate(c);
+      if (rc) return rc;
+      ncclResult_t nr = rccl()->AllGather(send, recv, bytes, ncclUint8, cm->nccl, s);
+      if (nr != ncclSuccess) {
+        if (cm->group) cm->group->abort_task();
+        return c->fail(ATMRT_ERR_HIP, "ncclAllGather of %zu bytes per rank failed on rank %d: %s", bytes, cm->rank, rccl()->GetErrorString(nr));
+      }
       return ATMRT_OK;
+    }
     case ATMRT_ROUTE_PEER: {
       // one process: every device writes its tile into every peer's buffer.  A failing rank still passes both barriers.
       MultiGroup* g = cm->group;
@@ -419,31 +512,83 @@ int ensure_comm_events(atmrt_ctx* c) {
   return ATMRT_OK;
 }
 
-// geometry of the tiles of the frame the context is configured for
+// The first collective of a communicator, run at set-up time where a host can still choose another transport: every rank sends
+// its rank number, every rank must find 0 .. world - 1 in order.  RCCL has no time-out of its own, so the wait is a poll with one
+// (ATMRT_COMM_PROBE_TIMEOUT seconds, default 180: the first collective of an 8-rank communicator builds its rings and can take
+// tens of seconds); a communicator that timed out is aborted (ncclCommAbort) and given up.
+int comm_probe(atmrt_ctx* c) {
+  Comm* cm = c->comm;
+  Rccl* r = rccl();
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, cm->d_small.reserve(512 + 8 * (size_t)cm->world));
+  uint64_t* d_mine = cm->d_small.as<uint64_t>();
+  uint64_t* d_all = d_mine + 64;
+  const uint64_t mine = 0xa7e0000000000000ull | (uint64_t)cm->rank;
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(d_mine, &mine, 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemsetAsync(d_all, 0, 8 * (size_t)cm->world, s));
+  int rc = group_gate(c);
+  if (rc) return rc;
+  ncclResult_t nr = r->AllGather(d_mine, d_all, 8, ncclUint8, cm->nccl, s);
+  if (nr != ncclSuccess) {
+    if (cm->group) cm->group->abort_task();
+    return c->fail(ATMRT_ERR_HIP, "the probe ncclAllGather failed on rank %d: %s", cm->rank, r->GetErrorString(nr));
+  }
+  const char* env = getenv("ATMRT_COMM_PROBE_TIMEOUT");
+  const double limit = env && atof(env) > 0.0 ? atof(env) : 180.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return c->fail(ATMRT_ERR_HIP, "the probe collective failed on rank %d: %s", cm->rank, hipGetErrorString(q));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      if (r->CommAbort) (void)r->CommAbort(cm->nccl);
+      cm->nccl = nullptr; // aborted (or, without ncclCommAbort, abandoned): never touched again
+      if (cm->group && (size_t)cm->rank < cm->group->nccl.size()) cm->group->nccl[(size_t)cm->rank] = nullptr;
+      if (cm->group) cm->group->abort_task();
+      return c->fail(ATMRT_ERR_HIP, "the probe collective of rank %d did not complete within %.0f s (ATMRT_COMM_PROBE_TIMEOUT)", cm->rank, limit);
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  std::vector<uint64_t> all((size_t)cm->world);
+  HIP_TRY(c, hipMemcpy(all.data(), d_all, 8 * (size_t)cm->world, hipMemcpyDeviceToHost));
+  for (int g = 0; g < cm->world; g++)
+    if (all[(size_t)g] != (0xa7e0000000000000ull | (uint64_t)g))
+      return c->fail(ATMRT_ERR_HIP, "the probe collective delivered %016llx where rank %d's word belongs", (unsigned long long)all[(size_t)g], g);
+  return ATMRT_OK;
+}
+
+// geometry of the tiles of the frame the context is about to generate
 int frame_geometry(atmrt_ctx* c) {
   Comm* cm = c->comm;
   if (!c->have_params) return c->fail(ATMRT_ERR_STATE, "atmrt_set_params has not been called");
   const int W = c->params.width, H = c->params.height, G = cm->world;
   if (W < G) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "image width %d is less than the %d ranks: a rank would be left without a column", W, G);
+  comm_tiling(cm, W);
+  cm->cols_frame = cm->cols;
   int wl_max = 0;
-  for (int g = 0; g < G; g++) wl_max = std::max(wl_max, shard_begin(W, g + 1, G) - shard_begin(W, g, G));
+  for (int g = 0; g < G; g++) wl_max = std::max(wl_max, cm->cols[(size_t)g + 1] - cm->cols[(size_t)g]);
   cm->W = W, cm->H = H, cm->wl_max = wl_max;
-  cm->slab_bytes = pad256((size_t)H * wl_max * (N_F64_PLANES * 8 + 4));
+  cm->slab_bytes = pad256((size_t)H * wl_max * (N_F64_PLANES * 8 + 4)) + SLAB_TRAILER_BYTES;
   return ATMRT_OK;
 }
 
 // Phase A of a shared frame: this rank's tile into its slab — the nine planes the generators write, back to back in ONE buffer
-// (84 B per pixel), so that one collective moves them all.
+// (84 B per pixel), so that one collective moves them all.  Every buffer the frame's exchange will need is reserved HERE, before
+// any rank can be inside a collective (group_gate).
 int tile_generate(atmrt_ctx* c, uint64_t* ray_steps, double* device_ms) {
   int rc = frame_geometry(c);
   if (rc) return rc;
   if ((rc = ensure_comm_events(c))) return rc;
   Comm* cm = c->comm;
   cm->image_valid = false;
+  cm->exchanged = false;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, cm->d_slab.reserve(cm->slab_bytes));
-  int c0 = 0, c1 = 0;
-  comm_columns(c, cm->W, &c0, &c1);
+  HIP_TRY(c, cm->d_gathered.reserve(cm->slab_bytes * (size_t)cm->world));
+  HIP_TRY(c, cm->d_tiling.reserve(4 * ((size_t)cm->world + 1)));
+  HIP_TRY(c, cm->d_small.reserve(512 + 8 * (size_t)cm->world));
+  const int c0 = cm->cols_frame[(size_t)cm->rank], c1 = cm->cols_frame[(size_t)cm->rank + 1];
   const size_t ps = (size_t)cm->H * (size_t)(c1 - c0);
   double* base = cm->d_slab.as<double>();
   DensePlanes& d = cm->slab_planes;
@@ -454,12 +599,39 @@ int tile_generate(atmrt_ctx* c, uint64_t* ray_steps, double* device_ms) {
   return api_generate_tile(c, &cm->slab_planes, false, &nh, ray_steps, device_ms);
 }
 
+// After a frame: the tiling of the next one, from every tile's time (the same numbers on every rank).
+void tile_rebalance(Comm* cm) {
+  if (!cm->balance || cm->cols_pinned || cm->world < 2) return;
+  const int G = cm->world;
+  std::vector<double> ms((size_t)G);
+  double sum = 0.0, worst = 0.0;
+  for (int g = 0; g < G; g++) {
+    ms[(size_t)g] = cm->trailers[(size_t)g].tile_ms;
+    sum += ms[(size_t)g];
+    worst = std::max(worst, ms[(size_t)g]);
+  }
+  if (!(sum > 0.0) || !(worst * G > 1.01 * sum)) return; // balanced within 1 %: leave it (the times carry that much noise)
+  std::vector<int> next((size_t)G + 1);
+  if (tiles_rebalance(cm->W, G, cm->cols_frame.data(), ms.data(), next.data())) cm->cols = next;
+}
+
 // Phase B: the collective + the permutation into `image` (planes on this rank's device; NULL azimuth: take part, assemble nothing).
 int tile_exchange(atmrt_ctx* c, const atmrt_device_planes_t* image) {
   Comm* cm = c->comm;
   hipStream_t s = c->stream;
+  const int G = cm->world;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, cm->d_gathered.reserve(cm->slab_bytes * (size_t)cm->world));
+  SlabTrailer mine{};
+  mine.n_hits = c->last_packed ? c->last_nhits : 0;
+  mine.seq = cm->seq;
+  mine.tile_ms = c->timings.total_ms;
+  mine.packed = c->last_packed ? 1u : 0u;
+  mine.c0 = (uint32_t)cm->cols_frame[(size_t)cm->rank];
+  mine.c1 = (uint32_t)cm->cols_frame[(size_t)cm->rank + 1];
+  const size_t trailer_at = cm->slab_bytes - SLAB_TRAILER_BYTES;
+  HIP_TRY(c, hipMemcpyAsync(cm->d_slab.as<char>() + trailer_at, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(cm->d_tiling.ptr, cm->cols_frame.data(), 4 * ((size_t)G + 1), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipStreamSynchronize(s)); // both sources are host stack / vectors: done with them before anything else happens
   HIP_TRY(c, hipEventRecord(cm->ev_g0, s));
   int rc = comm_all_gather(c, cm->d_slab.ptr, cm->d_gathered.ptr, cm->slab_bytes);
   if (rc) return rc;
@@ -470,24 +642,49 @@ int tile_exchange(atmrt_ctx* c, const atmrt_device_planes_t* image) {
     img.lat = image->lat, img.lon = image->lon, img.distance = image->distance, img.elevation = image->elevation;
     img.path_length = image->path_length, img.normal = image->normal;
     hipLaunchKernelGGL(k_assemble_image, dim3(blocks_for((size_t)cm->W * cm->H)), dim3(256), 0, s, cm->d_gathered.as<char>(),
-                       cm->slab_bytes, cm->W, cm->H, cm->world, img);
+                       cm->slab_bytes, cm->W, cm->H, G, (const int*)cm->d_tiling.as<int>(), img);
     cm->last_image = img;
-    cm->image_valid = true;
   }
   HIP_TRY(c, hipEventRecord(cm->ev_a1, s));
+  cm->trailers.assign((size_t)G, SlabTrailer{});
+  HIP_TRY(c, hipMemcpy2DAsync(cm->trailers.data(), sizeof(SlabTrailer), cm->d_gathered.as<char>() + trailer_at, cm->slab_bytes,
+                              sizeof(SlabTrailer), (size_t)G, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   HIP_TRY(c, hipGetLastError());
+  // every rank must have contributed the same frame, cut the same way: anything else is a host that lost step (a rank that
+  // skipped a frame, changed its parameters alone) and would otherwise be a silently mixed image
+  uint64_t seq_max = 0;
+  for (const SlabTrailer& t : cm->trailers) seq_max = std::max(seq_max, t.seq);
+  for (int g = 0; g < G; g++) {
+    const SlabTrailer& t = cm->trailers[(size_t)g];
+    if (t.seq != mine.seq || t.packed != mine.packed || (int)t.c0 != cm->cols_frame[(size_t)g] || (int)t.c1 != cm->cols_frame[(size_t)g + 1]) {
+      cm->seq = seq_max + 1; // every rank sees the same trailers and takes the same number: the next frame is in step again
+      cm->cols_W = -1;       // and cut into equal tiles
+      return c->fail(ATMRT_ERR_STATE, "rank %d contributed frame %llu, columns [%u, %u), lists %u where rank %d has frame %llu, columns [%d, %d), "
+                                      "lists %u: the ranks were out of step (this frame is void, the next one is in step again)", g,
+                     (unsigned long long)t.seq, t.c0, t.c1, t.packed, cm->rank, (unsigned long long)mine.seq, cm->cols_frame[(size_t)g],
+                     cm->cols_frame[(size_t)g + 1], mine.packed);
+    }
+  }
+  cm->seq++;
+  cm->exchanged = true;
+  cm->image_valid = image && image->azimuth;
   float g_ms = 0.f, a_ms = 0.f;
   HIP_TRY(c, hipEventElapsedTime(&g_ms, cm->ev_g0, cm->ev_g1));
   HIP_TRY(c, hipEventElapsedTime(&a_ms, cm->ev_g1, cm->ev_a1));
   cm->tm = atmrt_comm_timings_t{};
   cm->tm.gather_ms = g_ms;
   cm->tm.assemble_ms = a_ms;
-  cm->tm.tile_ms_max = cm->tm.tile_ms_min = c->timings.total_ms;
+  cm->tm.tile_ms_max = 0.0, cm->tm.tile_ms_min = 1e300;
+  for (const SlabTrailer& t : cm->trailers) {
+    cm->tm.tile_ms_max = std::max(cm->tm.tile_ms_max, t.tile_ms);
+    cm->tm.tile_ms_min = std::min(cm->tm.tile_ms_min, t.tile_ms);
+  }
   cm->tm.bytes_per_rank = cm->slab_bytes;
-  cm->tm.world = cm->world;
+  cm->tm.world = G;
   cm->tm.route = cm->nccl ? ATMRT_ROUTE_RCCL : cm->route;
   cm->tm.collectives = 1;
+  tile_rebalance(cm);
   return ATMRT_OK;
 }
 
@@ -495,44 +692,51 @@ bool image_planes_complete(const atmrt_device_planes_t& p) {
   return p.azimuth && p.elevation_angle && p.hit_count && p.lat && p.lon && p.distance && p.elevation && p.path_length && p.normal;
 }
 
-// The lists of the last shared frame on this rank: totals -> (optionally) the lists in the image's pixel order.
+// The lists of the last shared frame on this rank.  dst == NULL: the image's total only — known to every rank since the frame's own
+// collective (SlabTrailer), no communication.  dst != NULL: ONE collective, the all-gather of the packed lists, in which every
+// rank takes part whatever it wants for itself (dst->hit_offset == NULL: nothing; an error of its own — capacity too small, a missing
+// array, no image planes on this rank — is reported AFTER the collective): the ranks can never disagree about whether it happens,
+// because that depends only on numbers all of them hold — an image without a single trace point has no collective at all.
 int tile_hits(atmrt_ctx* c, const atmrt_device_hits_t* dst, uint64_t* n_total_out) {
   Comm* cm = c->comm;
   hipStream_t s = c->stream;
-  if (!c->last_valid) return c->fail(ATMRT_ERR_STATE, "atmrt_image_hits_device needs a frame: call atmrt_generate_image_device first");
+  if (!cm->exchanged || !c->last_valid)
+    return c->fail(ATMRT_ERR_STATE, "atmrt_image_hits_device needs a frame: call atmrt_generate_image_device first");
   if (!c->last_packed)
     return c->fail(ATMRT_ERR_STATE, "the last frame holds first-hit planes only (opaque scene): its trace points are the planes themselves");
-  if (dst && !cm->image_valid) return c->fail(ATMRT_ERR_STATE, "the image planes of the last frame were not assembled on this device");
-  HIP_TRY(c, hipSetDevice(c->device));
   const int G = cm->world;
-  // (1) every rank's total: 8 bytes each
-  HIP_TRY(c, cm->d_small.reserve(256 + 8 * (size_t)G + 64));
-  uint64_t* d_mine = cm->d_small.as<uint64_t>();
-  uint64_t* d_all = d_mine + 32;
-  const uint64_t n_local = c->last_nhits;
-  HIP_TRY(c, hipMemcpyAsync(d_mine, &n_local, 8, hipMemcpyHostToDevice, s));
-  int rc = comm_all_gather(c, d_mine, d_all, 8);
-  if (rc) return rc;
-  std::vector<uint64_t> totals((size_t)G);
-  HIP_TRY(c, hipMemcpyAsync(totals.data(), d_all, 8 * (size_t)G, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s)); // the one host synchronisation: buffer sizes must be known
   uint64_t n_total = 0, n_cap = 1;
-  for (uint64_t v : totals) n_total += v, n_cap = std::max(n_cap, v);
+  for (const SlabTrailer& t : cm->trailers) n_total += t.n_hits, n_cap = std::max<uint64_t>(n_cap, t.n_hits);
   if (n_total_out) *n_total_out = n_total;
-  cm->tm.collectives = 2;
   if (!dst) return ATMRT_OK;
-  if (dst->capacity < n_total)
-    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "capacity %llu is less than the %llu trace points of the image",
-                   (unsigned long long)dst->capacity, (unsigned long long)n_total);
-  if (!dst->hit_offset || !dst->lat || !dst->lon || !dst->distance || !dst->elevation || !dst->path_length || !dst->normal ||
-      !dst->color_tag || !dst->rgba)
-    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "every array pointer must be a device allocation");
-  // (2) this rank's lists into a block laid out for the largest rank, (3) one all-gather of the blocks
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool wants = dst->hit_offset != nullptr;
+  const size_t npx = (size_t)cm->W * cm->H;
+  if (n_total == 0) { // every rank knows: no collective.  The offsets of an image without trace points are all zero.
+    if (wants) {
+      HIP_TRY(c, hipMemsetAsync(dst->hit_offset, 0, npx * 8, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    return ATMRT_OK;
+  }
+  // this rank's own troubles, reported after it has done its part
+  const char* trouble = nullptr;
+  if (wants) {
+    if (!cm->image_valid) trouble = "the image planes of the last frame were not assembled on this device";
+    else if (dst->capacity < n_total) trouble = "capacity is less than the trace points of the image";
+    else if (!dst->lat || !dst->lon || !dst->distance || !dst->elevation || !dst->path_length || !dst->normal || !dst->color_tag || !dst->rgba)
+      trouble = "every array pointer must be a device allocation";
+  }
+  // (1) this rank's lists into a block laid out for the largest rank, (2) one all-gather of the blocks
   const size_t bb = HitBlock::bytes(n_cap);
+  const size_t ps = (size_t)cm->H * cm->wl_max; // stride of the per-rank offset tables
   HIP_TRY(c, cm->d_hits_send.reserve(bb));
   HIP_TRY(c, cm->d_hits_recv.reserve(bb * (size_t)G));
+  HIP_TRY(c, cm->d_loc_off.reserve(ps * (size_t)G * 8));
+  HIP_TRY(c, cm->d_scan_tmp.reserve((std::max(npx, ps) / 2048 + 4) * 8 + 64));
   char* blk = cm->d_hits_send.as<char>();
   const PackedHits& h = c->last_hits;
+  const uint64_t n_local = c->last_nhits;
   auto d2d = [&](size_t off, const void* from, size_t bytes) {
     return bytes ? hipMemcpyAsync(blk + off, from, bytes, hipMemcpyDeviceToDevice, s) : hipSuccess;
   };
@@ -544,28 +748,31 @@ int tile_hits(atmrt_ctx* c, const atmrt_device_hits_t* dst, uint64_t* n_total_ou
   HIP_TRY(c, d2d(HitBlock::off_f64(5, n_cap), h.normal, n_local * 24));
   HIP_TRY(c, d2d(HitBlock::off_f64(8, n_cap), h.rgba, n_local * 32));
   HIP_TRY(c, d2d(HitBlock::off_tag(n_cap), h.color_tag, n_local * 4));
-  if ((rc = comm_all_gather(c, blk, cm->d_hits_recv.ptr, bb))) return rc;
-  cm->tm.collectives = 3;
-  // (4) offsets: every rank's own (a scan of its hit_count plane inside the gathered slabs) and the image's
-  const size_t ps = (size_t)cm->H * cm->wl_max, npx = (size_t)cm->W * cm->H; // stride of the per-rank offset tables
-  HIP_TRY(c, cm->d_loc_off.reserve(ps * (size_t)G * 8));
-  HIP_TRY(c, cm->d_scan_tmp.reserve((std::max(npx, ps) / 2048 + 4) * 8 + 64));
-  uint64_t* tmp = cm->d_scan_tmp.as<uint64_t>();
-  unsigned long long* total = reinterpret_cast<unsigned long long*>(d_mine + 8); // scratch: the scans' grand totals are not needed
-  for (int g = 0; g < G; g++) {
-    const size_t n = (size_t)cm->H * (size_t)(shard_begin(cm->W, g + 1, G) - shard_begin(cm->W, g, G));
-    const uint32_t* counts = reinterpret_cast<const uint32_t*>(cm->d_gathered.as<char>() + (size_t)g * cm->slab_bytes + N_F64_PLANES * n * 8);
-    launch_scan_u32(counts, n, tmp, cm->d_loc_off.as<uint64_t>() + (size_t)g * ps, total, s);
+  int rc = comm_all_gather(c, blk, cm->d_hits_recv.ptr, bb);
+  if (rc) return rc;
+  cm->tm.collectives = 2;
+  if (wants && !trouble) {
+    // (3) offsets: every rank's own (a scan of its hit_count plane inside the gathered slabs) and the image's
+    uint64_t* tmp = cm->d_scan_tmp.as<uint64_t>();
+    unsigned long long* total = reinterpret_cast<unsigned long long*>(cm->d_small.as<uint64_t>() + 8); // scratch: the scans' grand totals are not needed
+    for (int g = 0; g < G; g++) {
+      const size_t n = (size_t)cm->H * (size_t)(cm->cols_frame[(size_t)g + 1] - cm->cols_frame[(size_t)g]);
+      const uint32_t* counts = reinterpret_cast<const uint32_t*>(cm->d_gathered.as<char>() + (size_t)g * cm->slab_bytes + N_F64_PLANES * n * 8);
+      launch_scan_u32(counts, n, tmp, cm->d_loc_off.as<uint64_t>() + (size_t)g * ps, total, s);
+    }
+    launch_scan_u32(cm->last_image.hit_count, npx, tmp, dst->hit_offset, total, s);
+    PackedHits out;
+    out.lat = dst->lat, out.lon = dst->lon, out.distance = dst->distance, out.elevation = dst->elevation;
+    out.path_length = dst->path_length, out.normal = dst->normal, out.color_tag = dst->color_tag, out.rgba = dst->rgba;
+    hipLaunchKernelGGL(k_gather_hits, dim3(blocks_for(npx)), dim3(256), 0, s, cm->d_hits_recv.as<char>(), bb, (size_t)n_cap,
+                       cm->d_loc_off.as<uint64_t>(), ps, cm->W, cm->H, G, (const int*)cm->d_tiling.as<int>(),
+                       (const uint32_t*)cm->last_image.hit_count, (const uint64_t*)dst->hit_offset, out);
   }
-  launch_scan_u32(cm->last_image.hit_count, npx, tmp, dst->hit_offset, total, s);
-  PackedHits out;
-  out.lat = dst->lat, out.lon = dst->lon, out.distance = dst->distance, out.elevation = dst->elevation;
-  out.path_length = dst->path_length, out.normal = dst->normal, out.color_tag = dst->color_tag, out.rgba = dst->rgba;
-  hipLaunchKernelGGL(k_gather_hits, dim3(blocks_for(npx)), dim3(256), 0, s, cm->d_hits_recv.as<char>(), bb, (size_t)n_cap,
-                     cm->d_loc_off.as<uint64_t>(), ps, cm->W, cm->H, G, (const uint32_t*)cm->last_image.hit_count,
-                     (const uint64_t*)dst->hit_offset, out);
   HIP_TRY(c, hipStreamSynchronize(s));
   HIP_TRY(c, hipGetLastError());
+  if (trouble)
+    return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "%s (the image holds %llu trace points, capacity %llu)", trouble, (unsigned long long)n_total,
+                   (unsigned long long)dst->capacity);
   return ATMRT_OK;
 }
 
@@ -573,17 +780,21 @@ int tile_hits(atmrt_ctx* c, const atmrt_device_hits_t* dst, uint64_t* n_total_ou
 int tile_draw(atmrt_ctx* c, const atmrt_coloring_t* coloring, uint8_t* rgb_image) {
   Comm* cm = c->comm;
   hipStream_t s = c->stream;
-  int rc = frame_geometry(c);
-  if (rc) return rc;
+  if (!cm->exchanged || !c->last_valid)
+    return c->fail(ATMRT_ERR_STATE, "atmrt_draw_image_gathered_device needs a frame: call atmrt_generate_image_device first");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t tile_bytes = pad256(3 * (size_t)cm->H * cm->wl_max);
   HIP_TRY(c, cm->d_rgb_tile.reserve(tile_bytes));
   HIP_TRY(c, cm->d_rgb_all.reserve(tile_bytes * (size_t)cm->world));
-  if ((rc = atmrt_draw_image_device(c, coloring, cm->d_rgb_tile.as<uint8_t>()))) return rc;
+  int rc = atmrt_draw_image_device(c, coloring, cm->d_rgb_tile.as<uint8_t>());
+  if (rc) {
+    if (cm->group) cm->group->abort_task();
+    return rc;
+  }
   if ((rc = comm_all_gather(c, cm->d_rgb_tile.ptr, cm->d_rgb_all.ptr, tile_bytes))) return rc;
   if (rgb_image)
     hipLaunchKernelGGL(k_assemble_rgb, dim3(blocks_for((size_t)cm->W * cm->H)), dim3(256), 0, s, cm->d_rgb_all.as<uint8_t>(), tile_bytes,
-                       cm->W, cm->H, cm->world, rgb_image);
+                       cm->W, cm->H, cm->world, (const int*)cm->d_tiling.as<int>(), rgb_image);
   HIP_TRY(c, hipStreamSynchronize(s));
   HIP_TRY(c, hipGetLastError());
   return ATMRT_OK;
@@ -618,7 +829,8 @@ void atmrt::multi_destroy(atmrt_ctx* parent) {
   // the children are destroyed on their own threads (their HIP objects belong to those devices), then the workers stop
   if (!g->workers.empty()) {
     g->run([&](atmrt_ctx* k, int i) {
-      if (k && k->comm && k->comm->nccl) (void)rccl()->CommDestroy(k->comm->nccl);
+      if ((size_t)i < g->nccl.size() && g->nccl[(size_t)i]) (void)rccl()->CommDestroy(g->nccl[(size_t)i]);
+      if ((size_t)i < g->nccl.size()) g->nccl[(size_t)i] = nullptr;
       if (k && k->comm) k->comm->nccl = nullptr;
       atmrt_ctx_destroy(k);
       g->kids[(size_t)i] = nullptr;
@@ -637,6 +849,31 @@ void atmrt::multi_destroy(atmrt_ctx* parent) {
   parent->multi = nullptr;
 }
 
+// direct device-to-device copies where the topology allows them (the peer-copy route)
+static void multi_enable_peer_access(MultiGroup* g) {
+  const size_t n = g->devices.size();
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = 0; j < n; j++) {
+      int can = 0;
+      if (g->devices[i] == g->devices[j] || hipDeviceCanAccessPeer(&can, g->devices[i], g->devices[j]) != hipSuccess || !can) continue;
+      if (hipSetDevice(g->devices[i]) == hipSuccess) (void)hipDeviceEnablePeerAccess(g->devices[j], 0);
+      (void)hipGetLastError(); // "already enabled" is fine
+    }
+  (void)hipSetDevice(g->devices[0]);
+}
+
+// RCCL let the context down (set-up, its probe collective, or an all-gather that returned an error): the devices of one process
+// can always exchange their tiles by device-to-device copies.  The communicators stay where they are until the context goes.
+static void multi_demote_to_peer(atmrt_ctx* parent) {
+  MultiGroup* g = parent->multi;
+  for (atmrt_ctx* k : g->kids) {
+    k->comm->nccl = nullptr;
+    k->comm->route = ATMRT_ROUTE_PEER;
+  }
+  g->demoted = parent->error;
+  multi_enable_peer_access(g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -650,6 +887,15 @@ extern "C" int atmrt_comm_unique_id(uint8_t id[ATMRT_COMM_ID_BYTES]) {
   if (rc != ncclSuccess) return api_create_fail(ATMRT_ERR_HIP, std::string("ncclGetUniqueId: ") + r->GetErrorString(rc));
   memcpy(id, &u, sizeof u);
   return ATMRT_OK;
+}
+
+extern "C" int atmrt_comm_available(void) { return rccl()->handle ? 1 : 0; }
+
+// re-tile after unbalanced frames?  ATMRT_TILE_BALANCE=0 / 1 overrides the default of the launch model
+static bool balance_default(bool fallback) {
+  const char* env = getenv("ATMRT_TILE_BALANCE");
+  if (env && *env) return atoi(env) != 0;
+  return fallback;
 }
 
 extern "C" int atmrt_ctx_comm_init_rank(atmrt_ctx* c, const uint8_t id[ATMRT_COMM_ID_BYTES], int32_t rank, int32_t world) {
@@ -668,6 +914,13 @@ extern "C" int atmrt_ctx_comm_init_rank(atmrt_ctx* c, const uint8_t id[ATMRT_COM
     return c->fail(ATMRT_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, r->GetErrorString(nr));
   }
   c->comm->route = ATMRT_ROUTE_RCCL;
+  c->comm->balance = balance_default(world > 1);
+  // the communicator's first collective runs HERE, where the host can still take another transport (atmrt_ctx_comm_init_external*)
+  if ((rc = comm_probe(c))) {
+    const std::string why = c->error;
+    comm_destroy(c);
+    return c->fail(rc, "%s", why.c_str());
+  }
   return ATMRT_OK;
 }
 
@@ -678,6 +931,7 @@ extern "C" int atmrt_ctx_comm_init_external(atmrt_ctx* c, int32_t rank, int32_t 
   c->comm->ext = fn;
   c->comm->ext_user = user;
   c->comm->route = ATMRT_ROUTE_EXTERNAL;
+  c->comm->balance = balance_default(false); // ranks that may share a device (a rehearsal): their times say nothing
   return ATMRT_OK;
 }
 
@@ -688,6 +942,7 @@ extern "C" int atmrt_ctx_comm_init_external_device(atmrt_ctx* c, int32_t rank, i
   c->comm->ext_dev = fn;
   c->comm->ext_user = user;
   c->comm->route = ATMRT_ROUTE_EXTERNAL_DEVICE;
+  c->comm->balance = balance_default(world > 1);
   return ATMRT_OK;
 }
 
@@ -750,17 +1005,21 @@ extern "C" int atmrt_ctx_create_multi(atmrt_ctx** out, const int32_t* devices, i
       return api_create_fail(ATMRT_ERR_HIP, "ATMRT_GATHER=rccl: " + why);
     }
   }
-  if (n > 1 && g->kids[0]->comm->route == ATMRT_ROUTE_PEER) { // direct device-to-device copies where the topology allows them
-    for (int i = 0; i < n; i++)
-      for (int j = 0; j < n; j++) {
-        int can = 0;
-        if (devices[i] == devices[j] || hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) continue;
-        if (hipSetDevice(devices[i]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[j], 0);
-        (void)hipGetLastError(); // "already enabled" is fine
-      }
-    (void)hipSetDevice(devices[0]);
-  }
+  for (int i = 0; i < n; i++) g->kids[(size_t)i]->comm->balance = balance_default(distinct && n > 1);
   for (int i = 0; i < n; i++) g->workers.emplace_back([g, i] { g->worker(i); });
+  if (g->kids[0]->comm->route == ATMRT_ROUTE_RCCL && n > 1) {
+    // the communicators' first collective, now: a failure here (or a hang: comm_probe's watchdog) falls back to peer copies
+    rc = multi_forward(parent, [&](atmrt_ctx* k) { return comm_probe(k); });
+    if (rc) {
+      if (force_rccl) {
+        const std::string why = parent->error;
+        atmrt_ctx_destroy(parent);
+        return api_create_fail(ATMRT_ERR_HIP, "ATMRT_GATHER=rccl: " + why);
+      }
+      multi_demote_to_peer(parent);
+    }
+  }
+  if (n > 1 && g->kids[0]->comm->route == ATMRT_ROUTE_PEER) multi_enable_peer_access(g);
   *out = parent;
   return ATMRT_OK;
 }
@@ -777,7 +1036,14 @@ extern "C" int atmrt_generate_image_device(atmrt_ctx* c, const atmrt_device_plan
     std::vector<double> ms(n, 0.0);
     int rc = multi_forward(c, [&](atmrt_ctx* k) { return tile_generate(k, &steps[(size_t)k->comm->rank], &ms[(size_t)k->comm->rank]); });
     if (rc) return rc; // no collective has started: nobody waits for the rank that failed
-    if ((rc = multi_forward(c, [&](atmrt_ctx* k) { return tile_exchange(k, &image[(size_t)k->comm->rank]); }))) return rc;
+    rc = multi_forward(c, [&](atmrt_ctx* k) { return tile_exchange(k, &image[(size_t)k->comm->rank]); });
+    if (rc && n > 1 && g->kids[0]->comm->route == ATMRT_ROUTE_RCCL && !(getenv("ATMRT_GATHER") && !strcmp(getenv("ATMRT_GATHER"), "rccl"))) {
+      // ncclAllGather returned an error (every device was released at the gate or came back with it): the tiles are still in
+      // their slabs — exchange them by device-to-device copies, now and from now on
+      multi_demote_to_peer(c);
+      rc = multi_forward(c, [&](atmrt_ctx* k) { return tile_exchange(k, &image[(size_t)k->comm->rank]); });
+    }
+    if (rc) return rc;
     atmrt_comm_timings_t tm = g->kids[0]->comm->tm;
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) {
@@ -803,13 +1069,20 @@ extern "C" int atmrt_generate_image_device(atmrt_ctx* c, const atmrt_device_plan
 extern "C" int atmrt_image_hits_device(atmrt_ctx* c, const atmrt_device_hits_t* dst, uint64_t* n_hits) {
   if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
   if (c->multi) {
-    std::vector<uint64_t> totals(c->multi->kids.size(), 0);
+    MultiGroup* g = c->multi;
+    if (!dst) { // the total: every device holds it since the frame's own collective
+      int rc = tile_hits(g->kids[0], nullptr, n_hits);
+      if (rc) c->error = g->kids[0]->error;
+      return rc;
+    }
+    // every device takes part in the lists' collective, whatever the caller wants on it (hit_offset NULL: nothing)
+    std::vector<uint64_t> totals(g->kids.size(), 0);
     int rc = multi_forward(c, [&](atmrt_ctx* k) {
       const size_t i = (size_t)k->comm->rank;
-      return tile_hits(k, dst && dst[i].lat ? &dst[i] : nullptr, &totals[i]);
+      return tile_hits(k, &dst[i], &totals[i]);
     });
     if (n_hits) *n_hits = totals[0];
-    c->multi->tm.collectives = c->multi->kids[0]->comm->tm.collectives;
+    g->tm.collectives = g->kids[0]->comm->tm.collectives;
     return rc;
   }
   if (!c->comm) return atmrt_last_hits_device(c, dst, n_hits); // one device: the tile's lists are the image's
@@ -836,6 +1109,74 @@ extern "C" int atmrt_last_comm_timings(atmrt_ctx* c, atmrt_comm_timings_t* out) 
   return ATMRT_OK;
 }
 
+extern "C" int atmrt_ctx_tile_columns(atmrt_ctx* c, int32_t index, int32_t* col_begin, int32_t* col_end) {
+  if (!c || !col_begin || !col_end) return ATMRT_ERR_INVALID_ARGUMENT;
+  const Comm* cm = c->multi ? (index >= 0 && index < multi_size(c) ? multi_child(c, index)->comm : nullptr) : c->comm;
+  if (c->multi && !cm) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "device index %d outside the context's %d devices", index, multi_size(c));
+  if (!cm) { // a plain context: the whole width (or the caller's own shard)
+    if (!c->have_params) return c->fail(ATMRT_ERR_STATE, "atmrt_set_params has not been called");
+    const bool whole = c->params.col_begin == 0 && c->params.col_end == 0;
+    *col_begin = whole ? 0 : c->params.col_begin;
+    *col_end = whole ? c->params.width : c->params.col_end;
+    return ATMRT_OK;
+  }
+  const int g = c->multi ? cm->rank : (index < 0 ? cm->rank : index);
+  if (g < 0 || g >= cm->world) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "rank %d outside the %d ranks", g, cm->world);
+  const std::vector<int>& cols = cm->exchanged ? cm->cols_frame : cm->cols;
+  if ((int)cols.size() != cm->world + 1) return c->fail(ATMRT_ERR_STATE, "no frame has been tiled yet");
+  *col_begin = cols[(size_t)g];
+  *col_end = cols[(size_t)g + 1];
+  return ATMRT_OK;
+}
+
+extern "C" int atmrt_tiles_rebalance(int32_t width, int32_t n_tiles, const int32_t* cols, const double* tile_ms, int32_t* cols_out) {
+  if (!cols || !tile_ms || !cols_out || n_tiles < 1 || width < n_tiles) return ATMRT_ERR_INVALID_ARGUMENT;
+  return tiles_rebalance(width, n_tiles, cols, tile_ms, cols_out) ? ATMRT_OK : ATMRT_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int atmrt_debug_set_tiling(atmrt_ctx* c, const int32_t* cols, int32_t n) {
+  if (!c) return ATMRT_ERR_INVALID_ARGUMENT;
+  auto set = [&](atmrt_ctx* k) {
+    Comm* cm = k->comm;
+    if (!cols) { // back to the library's own tiling
+      cm->cols_W = -1;
+      cm->cols_pinned = false;
+      return (int)ATMRT_OK;
+    }
+    if (n != cm->world + 1 || cols[0] != 0) return k->fail(ATMRT_ERR_INVALID_ARGUMENT, "a tiling of %d ranks is %d ascending boundaries from 0 to the width", cm->world, cm->world + 1);
+    for (int g = 0; g < cm->world; g++)
+      if (cols[g + 1] <= cols[g]) return k->fail(ATMRT_ERR_INVALID_ARGUMENT, "tile %d is empty", g);
+    cm->cols.assign(cols, cols + n);
+    cm->cols_W = cols[n - 1];
+    cm->cols_pinned = true;
+    return (int)ATMRT_OK;
+  };
+  if (c->multi) {
+    for (int i = 0; i < multi_size(c); i++) {
+      const int rc = set(multi_child(c, i));
+      if (rc) {
+        c->error = multi_child(c, i)->error;
+        return rc;
+      }
+    }
+    return ATMRT_OK;
+  }
+  if (!c->comm) return c->fail(ATMRT_ERR_STATE, "a plain context has no tiling: use col_begin / col_end");
+  return set(c);
+}
+
+extern "C" int atmrt_debug_fail_next_collective(atmrt_ctx* c, int32_t index, int32_t nth) {
+  if (!c || nth < 0) return ATMRT_ERR_INVALID_ARGUMENT;
+  atmrt_ctx* k = c;
+  if (c->multi) {
+    if (index < 0 || index >= multi_size(c)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "device index %d outside the context's %d devices", index, multi_size(c));
+    k = multi_child(c, index);
+  }
+  if (!k->comm) return c->fail(ATMRT_ERR_STATE, "a plain context has no collective to fail");
+  k->comm->fail_countdown = nth;
+  return ATMRT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // multi-device context, host consumer: Generator::generate -> Vec<Vec<ResultPixel>> in host memory
 // ---------------------------------------------------------------------------------------------
@@ -853,6 +1194,7 @@ int atmrt::multi_generate(atmrt_ctx* parent, atmrt_result_t* out) {
     int r = ensure_comm_events(k);
     if (r) return r;
     k->comm->image_valid = false;
+    k->comm->exchanged = false;
     return api_generate_tile(k, nullptr, true, &nh[i], &steps[i], &ms[i]);
   });
   if (rc) return rc;
@@ -956,6 +1298,16 @@ int atmrt::multi_generate(atmrt_ctx* parent, atmrt_result_t* out) {
     tm.bytes_per_rank = std::max<uint64_t>(tm.bytes_per_rank, (uint64_t)k->last_npx * 20 + nh[i] * 100);
   }
   g->tm = tm;
+  // the next frame's tiling from this frame's tile times (what tile_exchange does from the gathered trailers)
+  Comm* c0m = g->kids[0]->comm;
+  if (c0m->balance && !c0m->cols_pinned && n > 1 && tm.tile_ms_max * (double)n > 0.0) {
+    std::vector<double> tms(n);
+    double sum = 0.0;
+    for (size_t i = 0; i < n; i++) sum += (tms[i] = g->kids[i]->timings.total_ms);
+    std::vector<int> next(n + 1);
+    if (tm.tile_ms_max * (double)n > 1.01 * sum && tiles_rebalance(W, (int)n, c0m->cols.data(), tms.data(), next.data()))
+      for (atmrt_ctx* k : g->kids) k->comm->cols = next;
+  }
   return ATMRT_OK;
 }
 

@@ -98,6 +98,24 @@ class Context:
         out["route"] = _abi.ROUTES.get(out["route"], out["route"])
         return out
 
+    def tile_columns(self, index=-1):
+        """[c0, c1) of a tile (atmrt_ctx_tile_columns): of the last exchanged frame, else of the next one."""
+        c0, c1 = C.c_int32(), C.c_int32()
+        self.check(self.lib.atmrt_ctx_tile_columns(self.handle, index, C.byref(c0), C.byref(c1)))
+        return c0.value, c1.value
+
+    def set_tiling(self, cols):
+        """Test hook (atmrt_debug_set_tiling): the next frames use exactly these world + 1 column boundaries; None: the library's own."""
+        if cols is None:
+            self.check(self.lib.atmrt_debug_set_tiling(self.handle, None, 0))
+        else:
+            arr = (C.c_int32 * len(cols))(*[int(v) for v in cols])
+            self.check(self.lib.atmrt_debug_set_tiling(self.handle, arr, len(cols)))
+
+    def fail_next_collective(self, index=0, nth=1):
+        """Test hook (atmrt_debug_fail_next_collective)."""
+        self.check(self.lib.atmrt_debug_fail_next_collective(self.handle, index, nth))
+
     def check(self, rc):
         if rc != 0:
             raise AtmrtError(rc, self.lib.atmrt_last_error(self.handle).decode())
@@ -247,15 +265,18 @@ class Generator:
         self.ctx.check(self.ctx.lib.atmrt_generate_image_device(self.ctx.handle, arr, C.byref(steps), C.byref(ms)))
         return steps.value, ms.value
 
-    def image_hits_device(self, height, width, device=None):
+    def image_hits_device(self, height, width, skip=()):
         """The trace-point lists of the frame generate_image_device just produced, in the image's pixel order, as torch tensors on
-        `device` (default: the context's): atmrt_image_hits_device.  Collective over the ranks of a rank context."""
+        every device of the context (one dict for a plain or rank context, a list for a multi-device one; the devices whose index
+        is in `skip` take part in the exchange but get nothing: None): atmrt_image_hits_device.  The total is known to every rank
+        since the frame's own collective (no communication); the fill is ONE collective over the ranks."""
         import torch
         n = C.c_uint64()
         self.ctx.check(self.ctx.lib.atmrt_image_hits_device(self.ctx.handle, None, C.byref(n)))
-        devs = self.ctx.devices if device is None else [device]
-        ts = [_hit_tensors(n.value, height, width, torch.device("cuda", d)) for d in devs]
-        pods = (_abi.DeviceHits * len(ts))(*[_abi.DeviceHits(capacity=n.value, **{k: v.data_ptr() for k, v in t.items()}) for t in ts])
+        devs = self.ctx.devices
+        ts = [None if i in skip else _hit_tensors(n.value, height, width, torch.device("cuda", d)) for i, d in enumerate(devs)]
+        pods = (_abi.DeviceHits * len(ts))(*[_abi.DeviceHits() if t is None else
+                                             _abi.DeviceHits(capacity=n.value, **{k: v.data_ptr() for k, v in t.items()}) for t in ts])
         self.ctx.check(self.ctx.lib.atmrt_image_hits_device(self.ctx.handle, pods, None))
         return ts[0] if len(ts) == 1 else ts
 

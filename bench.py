@@ -132,7 +132,9 @@ def main():
         if backend == "gloo":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        # a rank that never arrives must end the job, not hang it: torch's watchdog aborts after the time-out
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("ATMRT_BENCH_TIMEOUT", "900"))))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-marching library has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -165,24 +167,33 @@ def main():
             # the library's exchange and assembly, but the bytes moved by torch.distributed's communicator (device tensors)
             ctx.comm_init_external_device(rank, world, generators.torch_device_all_gather(dist, dev))
         else:
+            # Every step of the bootstrap is agreed on by ALL ranks before any of them enters a collective of the library's own
+            # communicator: (1) can RCCL be loaded here? — a local, non-collective check, MIN-reduced; (2) rank 0's id, with its
+            # own ok flag; (3) ncclCommInitRank + the probe all-gather the library runs inside it (with a time-out), MIN-reduced.
+            # Any no: every rank hands its device buffers to torch.distributed's communicator instead.
             ident = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-            ok = torch.ones(1, dtype=torch.int32, device=dev)
-            try:
-                if rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
-            except Exception as exc:  # RCCL not loadable from the library: every rank must take the same road
-                log(f"[rank {rank}] atmrt_comm_unique_id failed ({exc}); falling back to torch.distributed's communicator")
-                ok.zero_()
-            dist.broadcast(ok, 0)
-            dist.broadcast(ident, 0)
+            ok = torch.tensor([int(ctx.lib.atmrt_comm_available())], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
+                try:
+                    if rank == 0:
+                        ident.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+                except Exception as exc:
+                    log(f"[rank {rank}] atmrt_comm_unique_id failed ({exc})")
+                    ok.zero_()
+                dist.broadcast(ok, 0)
+                dist.broadcast(ident, 0)
+            else:
+                log(f"[rank {rank}] RCCL cannot be loaded by the library on some rank")
             if int(ok.item()):
                 try:
                     ctx.comm_init_rank(bytes(ident.cpu().numpy()), rank, world)
                 except Exception as exc:
                     log(f"[rank {rank}] atmrt_ctx_comm_init_rank failed ({exc})")
                     ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # one rank without its communicator: nobody uses it
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # one rank without its communicator: nobody uses it
             if not int(ok.item()):
+                log(f"[rank {rank}] falling back to torch.distributed's communicator for the exchange")
                 ctx.close()  # a context holds at most one communicator: start over
                 ctx = generators.Context(local_rank)
                 ctx.comm_init_external_device(rank, world, generators.torch_device_all_gather(dist, dev))
@@ -211,7 +222,7 @@ def main():
                 ct = ctx.comm_timings()
                 tm["gather_ms"] = ct["gather_ms"] + ct["assemble_ms"]
                 comm_info.update(ct)
-                if lists and multi_hit:  # pixels with several trace points: the variable-length lists as well (2 more collectives)
+                if lists and multi_hit:  # pixels with several trace points: the variable-length lists as well (1 more collective)
                     gathered_hits[0] = gen.image_hits_device(H, W)
                     comm_info.update(ctx.comm_timings())
             tm["terrain_lookups"] = gen.last_stats()["terrain_lookups"]
@@ -283,6 +294,10 @@ def main():
         the 78.6 TFLOP/s FP64 vector peak.  `issue_slot_frac` is the other view: ALL VALU lane-instructions per second (moves,
         compares, integer index arithmetic included) against the issue peak of 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz."""
         mean = lambda k: float(np.mean([p[k] for p in phase]))
+        # this rank's tile in the last frame: the library re-cuts the tiling when the tiles' times differ (atmrt_ctx_tile_columns)
+        c0, c1 = ctx.tile_columns() if distributed else (0, W)
+        wl = c1 - c0
+        local = {k: (v[..., c0:c1]) for k, v in image.items()}
         steps_per_launch = mean("ray_steps")
         lookups = mean("terrain_lookups")
         hits = float((local["hit_count"] > 0).sum().item())  # recorded crossings of this rank's columns in the last frame (opaque terrain: one per hit pixel)
@@ -377,7 +392,8 @@ def main():
         # inside ms_per_step: one all-gather of the 84 B/pixel slab + the permutation into the [H][W] image (+ the lists of a multi-hit frame),
         # all of it in C++ below the C ABI (csrc/atmrt_multi.hip); the figures are the library's own HIP events, slowest rank
         result["all_gather_ms_per_step"] = gather_ms.get(args.generator)
-        result["all_gather_collectives_per_step"] = 1 + (2 if multi_hit else 0)
+        result["all_gather_collectives_per_step"] = comm_info.get("collectives")  # as the library counted them: 1 (+ 1 for the lists)
+        result["tile_columns"] = list(ctx.tile_columns())  # this rank's tile in the last frame (the library re-cuts unbalanced tilings)
         result["world_size_seen"] = dist.get_world_size()
         result["comm"] = {k: comm_info.get(k) for k in ("route", "world", "bytes_per_rank", "gather_ms", "assemble_ms", "tile_ms_max")}
     if not args.only and args.generator == "Rectilinear":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ATMRT_ABI_VERSION 4
+#define ATMRT_ABI_VERSION 5
 
 typedef enum atmrt_status {
   ATMRT_OK = 0,
@@ -338,11 +338,14 @@ int atmrt_draw_image_device(atmrt_ctx* ctx, const atmrt_coloring_t* coloring, ui
  *      link; no collective, the consumer being the host).  atmrt_generate_image_device leaves the whole frame in the HBM of EVERY
  *      device: one ncclAllGather (RCCL over xGMI) of the tiles' planes + a permutation kernel into the [H][W] planes.
  *  (2) ONE PROCESS PER GPU (torchrun, MPI): every rank creates a plain context, rank 0 obtains atmrt_comm_unique_id and hands it to
- *      the others through whatever the launcher offers, every rank calls atmrt_ctx_comm_init_rank; atmrt_generate_image_device is
- *      then collective over the ranks.  atmrt_generate / atmrt_generate_device on such a context return the rank's own tile.
+ *      the others through whatever the launcher offers, every rank calls atmrt_ctx_comm_init_rank (which also runs the
+ *      communicator's first collective, a probe with a time-out, so that a fabric that does not work is an error HERE, where the
+ *      host can still take atmrt_ctx_comm_init_external*); atmrt_generate_image_device is then collective over the ranks.  atmrt_generate / atmrt_generate_device on such a context return the rank's own tile.
  *
  * Frames whose pixels hold several trace points (terrain_alpha < 1, scene objects, InterpolatingRectilinear) also exchange the
- * variable-length lists: atmrt_image_hits_device (count -> scan -> offset on the device, one all-gather of the lists). */
+ * variable-length lists: atmrt_image_hits_device (count -> scan -> offset on the device, one all-gather of the lists).
+ * RCCL is resolved with dlopen("librccl.so.1") on first use: a process that already carries one under that SONAME (PyTorch's
+ * bundled librccl) shares it — one RCCL, one HIP runtime per process — any other finds ROCm's through the library's RUNPATH. */
 #define ATMRT_COMM_ID_BYTES 128
 /* ncclGetUniqueId: 128 opaque bytes for the other ranks' atmrt_ctx_comm_init_rank. */
 int atmrt_comm_unique_id(uint8_t id[ATMRT_COMM_ID_BYTES]);
@@ -371,8 +374,16 @@ int atmrt_ctx_device_count(const atmrt_ctx* ctx);
  * pointer is NULL is skipped).  ray_steps: of this rank (rank context) / of all devices (multi-device context). */
 int atmrt_generate_image_device(atmrt_ctx* ctx, const atmrt_device_planes_t* image, uint64_t* ray_steps, double* device_ms);
 /* The complete trace-point lists of that frame in the image's pixel order p = y W + x — atmrt_last_hits_device for the whole
- * image — on every device: `dst` like `image` above (entry i on devices[i]; hit_offset is [H][W]).  dst == NULL only queries
- * *n_hits (still collective).  Frames without lists (opaque terrain, no objects, not InterpolatingRectilinear): ATMRT_ERR_STATE. */
+ * image — on every device: `dst` like `image` above (entry i on devices[i]; hit_offset is [H][W]).
+ *   dst == NULL: only *n_hits, the image's total — every rank has known it since the frame's own collective (each tile's slab
+ *     carries its count): no communication, any rank may ask at any time.
+ *   dst != NULL: COLLECTIVE — every rank of the frame (every device of a multi-device context: one entry each) must make the
+ *     call; ONE all-gather of the packed lists, then count -> scan -> offset on the device.  A rank (or device entry) that wants
+ *     nothing for itself passes hit_offset == NULL and still takes part.  A rank's own mistake (capacity < *n_hits, a NULL array
+ *     while the image has trace points, no image planes assembled on it) is reported to that rank AFTER it has taken part, so
+ *     the others never wait for it.  An image without a single trace point has no collective at all: hit_offset is zero-filled,
+ *     the list arrays are not touched and may be NULL.
+ * Frames without lists (opaque terrain, no objects, not InterpolatingRectilinear): ATMRT_ERR_STATE on every rank. */
 int atmrt_image_hits_device(atmrt_ctx* ctx, const atmrt_device_hits_t* dst, uint64_t* n_hits);
 /* renderer::draw_image of every tile + an all-gather of the 3 B/pixel RGB8 tiles instead of the 84 B/pixel planes: rgb_device[i]
  * is [H][W][3] on devices[i] (NULL entries skipped). */
@@ -395,10 +406,28 @@ typedef struct atmrt_comm_timings {
   uint64_t bytes_per_rank;  /* what each rank contributed to the collective */
   int32_t world;
   int32_t route;            /* atmrt_gather_route */
-  int32_t collectives;      /* data-path collectives of the last frame (1 for an image, + 2 for its lists) */
+  int32_t collectives;      /* data-path collectives of the last frame (1 for an image, + 1 for its lists) */
   int32_t _pad;
 } atmrt_comm_timings_t;
 int atmrt_last_comm_timings(atmrt_ctx* ctx, atmrt_comm_timings_t* out);
+/* 1 when RCCL can be loaded in this process (no device work, not collective): what every rank of a launcher checks — and agrees
+ * on — BEFORE any of them enters the collective atmrt_ctx_comm_init_rank. */
+int atmrt_comm_available(void);
+/* The pixel columns [*col_begin, *col_end) of a tile: of the last frame that was exchanged, else of the next one.  A multi-device
+ * context: of device `index`; a rank context: of rank `index` (index < 0: its own); a plain context: its whole width or shard.
+ * Tiles start equal (rank g of G: [g W / G, (g + 1) W / G)) and are RE-CUT by the library after a frame whose slowest tile took
+ * more than 1 % longer than the mean — every rank from the same gathered tile times, so all agree without a message
+ * (ATMRT_TILE_BALANCE=0 keeps them equal; 1 forces re-cutting where it is off by default: devices listed twice, the host-buffer
+ * transport). */
+int atmrt_ctx_tile_columns(atmrt_ctx* ctx, int32_t index, int32_t* col_begin, int32_t* col_end);
+/* The re-cutting rule itself, a pure function: cols (n_tiles + 1 ascending boundaries, 0 .. width) and each tile's time ->
+ * boundaries that would have equalised the times had the cost per column been constant inside each tile. */
+int atmrt_tiles_rebalance(int32_t width, int32_t n_tiles, const int32_t* cols, const double* tile_ms, int32_t* cols_out);
+/* Test hooks.  set_tiling: the next frames use exactly these n = world + 1 boundaries (NULL: back to the library's own); on a
+ * rank context every rank must be given the same.  fail_next_collective: the nth data-path collective from now (1 = the next)
+ * fails on device `index` of a multi-device context / on this rank — before it is enqueued, as a refused ncclAllGather would. */
+int atmrt_debug_set_tiling(atmrt_ctx* ctx, const int32_t* cols, int32_t n);
+int atmrt_debug_fail_next_collective(atmrt_ctx* ctx, int32_t index, int32_t nth);
 
 /* ---- integrator / sampler harnesses (the reference's diagnostic subcommands) ---------------- */
 /* output-ray-paths (src/ray_path.rs:65-103): for each elevation angle [deg] step the ray n_steps

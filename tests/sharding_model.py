@@ -1,10 +1,10 @@
 """Pixel-column tile sharding across the GPUs of one node: rank g of G owns columns
 [g*W/G, (g+1)*W/G); rows and the terrain mosaic are replicated (pixels are independent, rectilinear.rs:32-37).
 
-SINCE ROUND 3 THE PRODUCT PATH IS C++: csrc/atmrt_multi.hip does all of this below the C ABI (atmrt_ctx_create_multi,
-atmrt_ctx_comm_init_rank, atmrt_generate_image_device, atmrt_image_hits_device — hand-written against RCCL), and bench.py uses
-that.  This module stays as the torch.distributed statement of the same exchange for hosts that drive their ranks from Python
-and as the CPU-testable model of the layout (tests/test_distributed_cpu.py: world_size 2 over gloo).
+TEST INFRASTRUCTURE, not product code: the product's exchange is C++ below the C ABI (csrc/atmrt_multi.hip:
+atmrt_ctx_create_multi, atmrt_ctx_comm_init_rank, atmrt_generate_image_device, atmrt_image_hits_device — hand-written against
+RCCL) and cannot run without a GPU.  This module is the torch.distributed statement of the same layout, the CPU-testable model
+that tests/test_distributed_cpu.py runs at world size 2 over gloo; nothing outside tests/ imports it.
 
 The only exchange is at the end of the frame and it is ONE collective: every rank's result planes live in one contiguous
 slab (`PlaneSlab`: 7 f64 planes + the planar normal + hit_count, 84 B per pixel), `ImageGather` all-gathers the slabs with a
@@ -58,7 +58,7 @@ class PlaneSlab:
 
     def device_planes(self):
         """atmrt_device_planes_t pointing into the slab."""
-        from . import _abi
+        from atm_raytracer_amd import _abi
         return _abi.DevicePlanes(**{k: v.data_ptr() for k, v in self.planes.items()})
 
 

@@ -44,7 +44,7 @@ def test_defaults_match_the_reference(lib):
     a = _abi.Atmosphere()
     lib.atmrt_atmosphere_us76(C.byref(a))
     assert a.n_functions == 7 and a.pressure == 101325.0 and a.temperature == 288.15 and a.functions[0].gradient == -0.0065
-    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 4
+    assert a.has_temperature_fixed_point == 1 and a.functions[6].altitude == 71000.0 and lib.atmrt_abi_version() == 5
 
 
 def test_build_info_names_the_sources_and_the_required_flags(lib):
@@ -94,3 +94,39 @@ def test_march_plan_of_frames_and_tiles(lib):
     ragged = plan(150, 61, 2308)
     assert ragged[1] == (150 * 61 + 63) // 64 and ragged[3] == ragged[1] * 64 * 196 + 64 + 4 * ragged[2]
     assert lib.atmrt_debug_march_plan(-1, 1, 1, 0, out) != 0
+
+
+def test_tiles_rebalance_is_a_pure_deterministic_rule(lib):
+    """atmrt_tiles_rebalance (what every rank evaluates on the same gathered tile times after a frame): boundaries move towards
+    the slow tiles, the result is a valid tiling of the same width, balanced inputs stay, bad inputs are refused, and widths never
+    fall below one column — also when one tile is a thousand times slower than the others."""
+    def rebalance(width, cols, ms):
+        n = len(ms)
+        out = (C.c_int32 * (n + 1))()
+        rc = lib.atmrt_tiles_rebalance(width, n, (C.c_int32 * (n + 1))(*cols), (C.c_double * n)(*ms), out)
+        return rc, list(out)
+
+    W = 4096
+    equal = [g * W // 8 for g in range(9)]
+    rc, same = rebalance(W, equal, [33.0] * 8)
+    assert rc == 0 and same == equal
+    # the last two tiles 5 % slower (the headline's low-sky columns): they get narrower, the others wider, total cost now level
+    ms = [32.2] * 6 + [33.7, 33.7]
+    rc, cols = rebalance(W, equal, ms)
+    assert rc == 0 and cols[0] == 0 and cols[-1] == W and all(b > a for a, b in zip(cols, cols[1:]))
+    widths = [b - a for a, b in zip(cols, cols[1:])]
+    assert widths[7] < 512 < widths[0] and widths[6] < 512
+    cost = [w * m / 512 for w, m in zip(widths, ms)]  # under the rule's own model: constant cost per column inside an old tile
+    assert max(cost) / (sum(cost) / 8) < 1.005, cost
+    assert rebalance(W, equal, ms)[1] == cols  # deterministic
+    # one pathological tile
+    rc, cols = rebalance(16, [0, 2, 4, 6, 8, 10, 12, 14, 16], [1.0] * 7 + [1000.0])
+    assert rc == 0 and cols[0] == 0 and cols[-1] == 16 and all(b > a for a, b in zip(cols, cols[1:]))
+    rc, cols = rebalance(8, list(range(9)), [1000.0] + [1.0] * 7)
+    assert rc == 0 and cols == list(range(9))  # nothing to give: every tile is one column wide
+    # refused: a non-positive or non-finite time, a tiling that does not span the width, an empty tile
+    assert rebalance(W, equal, [33.0] * 7 + [0.0])[0] != 0
+    assert rebalance(W, equal, [33.0] * 7 + [float("nan")])[0] != 0
+    assert rebalance(W, equal[:-1] + [W - 1], [33.0] * 8)[0] != 0
+    assert rebalance(W, [0, 512, 512] + equal[3:], [33.0] * 8)[0] != 0
+    assert lib.atmrt_comm_available() in (0, 1)

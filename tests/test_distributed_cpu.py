@@ -1,7 +1,9 @@
-"""The N > 1 path on the CPU: world_size 2 over gloo.  Each rank computes its pixel-column tile (here with the
-oracle standing in for the HIP library — the host logic under test is the sharding, the all-gather and the
-re-assembly in atm_raytracer_amd/sharding.py, exactly what bench.py runs over RCCL) and the gathered image must
-equal the unsharded frame."""
+"""The N > 1 path on the CPU: world_size 2 over gloo.  The product's exchange is C++ below the C ABI (csrc/atmrt_multi.hip:
+tiles assigned by the library, one ncclAllGather of the slabs, k_assemble_image, count -> scan -> offset for the lists) and
+cannot run without a GPU; what runs here is tests/sharding_model.py, the torch.distributed statement of the SAME layout — the
+column tiles, the rank-major slab all-gather, the permutation into [H][W] planes, the list merge — with the oracle standing in
+for the HIP library on each rank.  It is a model of the layout, kept as test infrastructure: nothing in the product imports
+it.  The gathered image must equal the unsharded frame."""
 import os
 import sys
 
@@ -36,7 +38,8 @@ def worker(rank, world, port, width, height, generator, queue):
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from atm_raytracer_amd import sharding, synth
+    import sharding_model as sharding
+    from atm_raytracer_amd import synth
     from oracle_binding import Oracle
     from util import run_oracle
     cfg, tiles = synth.scene("S2", width, height, generator=generator, max_distance=60_000.0, level=301)
@@ -95,7 +98,8 @@ def hits_worker(rank, world, port, width, height, queue):
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from atm_raytracer_amd import sharding, synth
+    import sharding_model as sharding
+    from atm_raytracer_amd import synth
     from oracle_binding import Oracle
     from util import run_oracle
     cfg, tiles = synth.scene("S2", width, height, generator="Fast", max_distance=60_000.0, level=301, terrain_alpha=0.4, tilt=-4.0)
@@ -139,7 +143,7 @@ def test_two_rank_variable_length_hit_lists(oracle_det):
 
 
 def test_assemble_layout():
-    from atm_raytracer_amd import sharding
+    import sharding_model as sharding
     g, h, wl = 4, 3, 5
     img = torch.arange(h * g * wl, dtype=torch.float64).reshape(h, g * wl)
     shards = torch.stack([img[:, r * wl:(r + 1) * wl] for r in range(g)])  # what all_gather_into_tensor produces
@@ -152,7 +156,7 @@ def test_assemble_layout():
 
 
 def test_plane_slab_views_alias_one_buffer():
-    from atm_raytracer_amd import sharding
+    import sharding_model as sharding
     slab = sharding.PlaneSlab(6, 4, torch.device("cpu"))
     assert slab.nbytes == 6 * 4 * 84 and set(slab.planes) == set(PLANES)
     slab.buf.zero_()

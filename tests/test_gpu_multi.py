@@ -141,7 +141,7 @@ def test_image_in_hbm_on_every_device(gpu_ctx, kind):
                     hits = gen.image_hits_device(H, W)
                     for h in (hits if isinstance(hits, list) else [hits]):
                         check_lists(h, want)
-                    assert ctx.comm_timings()["collectives"] == 3
+                    assert ctx.comm_timings()["collectives"] == 2  # the image's slabs (which carry the totals) + the lists' blocks
                 else:
                     n = C.c_uint64()
                     assert ctx.lib.atmrt_image_hits_device(ctx.handle, None, C.byref(n)) == _abi.ERR_STATE
@@ -288,3 +288,232 @@ def test_multi_context_errors_and_recovery(gpu_ctx, multi3):
     a, b = generators.atmosphere_sample(multi3, alt), generators.atmosphere_sample(gpu_ctx, alt)
     assert all(np.array_equal(a[k], b[k]) for k in a)
     assert multi3.lib.atmrt_ctx_device_count(multi3.handle) == 3 and gpu_ctx.lib.atmrt_ctx_device_count(gpu_ctx.handle) == 1
+
+
+def _lists_scene(width=90, height=33, generator="Rectilinear"):
+    return scene(generator, True, width=width, height=height)
+
+
+def test_partially_null_destinations_do_not_hang(gpu_ctx, multi3):
+    """atmrt_image_hits_device with dst = [pods0, NULL entry, pods2].  Every device takes part in the lists' collective
+    whatever the caller wants on it; the skipped device gets nothing; a device whose own arguments are wrong (capacity too small)
+    reports that AFTER taking part, and the others still get their lists."""
+    cfg, tiles = _lists_scene()
+    W, H = cfg.params.width, cfg.params.height
+    want = run_gpu(gpu_ctx, cfg, tiles)
+    multi3.check(multi3.lib.atmrt_terrain_clear(multi3.handle))
+    gen = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, multi3))
+    images = [generators.image_planes(H, W, torch.device("cuda", 0)) for _ in range(3)]
+    gen.generate_image_device([pod for _, pod in images])
+    hits = gen.image_hits_device(H, W, skip=(1,))
+    assert hits[1] is None
+    check_lists(hits[0], want)
+    check_lists(hits[2], want)
+    assert multi3.comm_timings()["collectives"] == 2
+    # the total needs no collective and can be asked any number of times, from a multi-device context ...
+    n = C.c_uint64()
+    for _ in range(3):
+        multi3.check(multi3.lib.atmrt_image_hits_device(multi3.handle, None, C.byref(n)))
+        assert n.value == want["n_hits"]
+    # ... a device whose capacity is too small fails alone, after the collective: the call reports it, the other devices hold the lists
+    ts = [generators._hit_tensors(want["n_hits"], H, W, torch.device("cuda", 0)) for _ in range(3)]
+    pods = (_abi.DeviceHits * 3)(*[_abi.DeviceHits(capacity=(5 if i == 1 else want["n_hits"]), **{k: v.data_ptr() for k, v in t.items()})
+                                   for i, t in enumerate(ts)])
+    assert multi3.lib.atmrt_image_hits_device(multi3.handle, pods, None) == _abi.ERR_INVALID_ARGUMENT
+    assert "capacity" in multi3.lib.atmrt_last_error(multi3.handle).decode()
+    check_lists(ts[0], want)
+    check_lists(ts[2], want)
+    # an image that was not assembled on a device (azimuth NULL) cannot have its lists there — reported, not hung
+    pods_img = [pod for _, pod in images]
+    pods_img[2] = _abi.DevicePlanes()
+    gen.generate_image_device(pods_img)
+    hits = gen.image_hits_device(H, W, skip=(2,))
+    check_lists(hits[0], want)
+    pods = (_abi.DeviceHits * 3)(*[_abi.DeviceHits(capacity=want["n_hits"], **{k: v.data_ptr() for k, v in t.items()}) for t in ts])
+    assert multi3.lib.atmrt_image_hits_device(multi3.handle, pods, None) == _abi.ERR_INVALID_ARGUMENT
+    assert "not assembled" in multi3.lib.atmrt_last_error(multi3.handle).decode()
+    check_lists(ts[1], want)
+
+
+@pytest.mark.parametrize("kind", ["multi", "rank"])
+def test_lists_of_a_frame_without_trace_points(gpu_ctx, multi3, kind):
+    """translucent terrain in a sky-only view — the frame has lists, and they are empty.  torch.empty(0).data_ptr() is 0:
+    NULL list arrays are fine when the image has no trace point, hit_offset comes back zero-filled, no collective runs."""
+    sky, tiles = synth.scene("S2", 64, 20, generator="Rectilinear", tilt=60.0, fov=20.0, max_distance=30_000.0, terrain_alpha=0.5)
+    ctx = multi3 if kind == "multi" else generators.Context(0)
+    try:
+        if kind == "rank":
+            ctx.comm_init_rank(ctx.comm_unique_id(), 0, 1)
+        ctx.check(ctx.lib.atmrt_terrain_clear(ctx.handle))
+        gen = generators.make_generator(generators.Params(sky), generators.Terrain.from_tiles(tiles, ctx))
+        images = [generators.image_planes(20, 64, torch.device("cuda", 0)) for _ in ctx.devices]
+        gen.generate_image_device([pod for _, pod in images])
+        hits = gen.image_hits_device(20, 64)
+        for h in (hits if isinstance(hits, list) else [hits]):
+            assert h["lat"].numel() == 0 and h["lat"].data_ptr() == 0
+            assert int(h["hit_offset"].abs().sum()) == 0
+        assert ctx.comm_timings()["collectives"] == 1
+        for planes, _ in images:
+            assert int(planes["hit_count"].sum()) == 0
+    finally:
+        if kind == "rank":
+            ctx.close()
+
+
+@pytest.mark.parametrize("nth", [1, 2], ids=["image-collective", "lists-collective"])
+def test_a_failing_collective_fails_the_frame_on_every_device_and_the_next_is_whole(gpu_ctx, multi3, nth):
+    """a COLLECTIVE (not a tile) fails on one device — injected where a refused ncclAllGather would return.  The
+    peer route: the failing device releases the others at their barrier, the call returns the failure, nothing hangs, and the next
+    frame (and its lists) is whole."""
+    cfg, tiles = _lists_scene()
+    W, H = cfg.params.width, cfg.params.height
+    want = run_gpu(gpu_ctx, cfg, tiles)
+    multi3.check(multi3.lib.atmrt_terrain_clear(multi3.handle))
+    gen = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, multi3))
+    images = [generators.image_planes(H, W, torch.device("cuda", 0)) for _ in range(3)]
+    multi3.fail_next_collective(index=1, nth=nth)
+    with pytest.raises(generators.AtmrtError) as e:
+        gen.generate_image_device([pod for _, pod in images])
+        gen.image_hits_device(H, W)
+    assert "injected" in str(e.value) and "device" in str(e.value)
+    if nth == 1:  # the frame is void: its lists cannot be asked for
+        n = C.c_uint64()
+        assert multi3.lib.atmrt_image_hits_device(multi3.handle, None, C.byref(n)) == _abi.ERR_STATE
+    gen.generate_image_device([pod for _, pod in images])
+    for planes, _ in images:
+        check_image(planes, want)
+    for h in gen.image_hits_device(H, W):
+        check_lists(h, want)
+
+
+def test_a_failing_collective_on_the_external_device_route(gpu_ctx):
+    """The same with two rank contexts and the host's own device transport: rank 1's collective fails before its callback runs;
+    rank 0's callback — a test double that waits for its peer — is released by the double's own abort and reports failure, so
+    both ranks return an error; after the double is reset the next frame is whole on both."""
+    world = 2
+    barrier = threading.Barrier(world)
+    shared, lock = {}, threading.Lock()
+    cfg, tiles = _lists_scene(width=70, height=31)
+    W, H = cfg.params.width, cfg.params.height
+    want = run_gpu(gpu_ctx, cfg, tiles)
+
+    dev = torch.device("cuda", 0)
+
+    def transport(rank):
+        def all_gather(send, recv, nbytes):
+            mine = torch.as_tensor(generators._DeviceBytes(send, nbytes), device=dev)
+            out = torch.as_tensor(generators._DeviceBytes(recv, nbytes * world), device=dev)
+            with lock:
+                shared[rank] = mine
+            barrier.wait(timeout=60)
+            for r in range(world):
+                out[r * nbytes:(r + 1) * nbytes].copy_(shared[r])
+            torch.cuda.synchronize(dev)
+            barrier.wait(timeout=60)
+        return all_gather
+
+    results, errors, failures = {}, [], {}
+    frame_gate = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            ctx = generators.Context(0)
+            ctx.comm_init_external_device(rank, world, transport(rank))
+            cfg_r, _ = _lists_scene(width=70, height=31)
+            gen = generators.make_generator(generators.Params(cfg_r), generators.Terrain.from_tiles(tiles, ctx))
+            planes, pod = generators.image_planes(H, W, torch.device("cuda", 0))
+            if rank == 1:
+                ctx.fail_next_collective(nth=1)
+            try:
+                gen.generate_image_device(pod)
+                failures[rank] = None
+            except generators.AtmrtError as exc:
+                failures[rank] = str(exc)
+                if rank == 1:
+                    barrier.abort()  # what a real transport's failure detector does for the peers of a dead rank
+            frame_gate.wait(timeout=120)
+            if rank == 0:
+                barrier.reset()
+            frame_gate.wait(timeout=120)
+            gen.generate_image_device(pod)
+            hits = gen.image_hits_device(H, W)
+            results[rank] = (planes, hits)
+            ctx.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+            frame_gate.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert "injected" in failures[1] and "callback returned" in failures[0]
+    for r in range(world):
+        check_image(results[r][0], want)
+        check_lists(results[r][1], want)
+
+
+@pytest.mark.parametrize("generator", GENERATORS)
+def test_tile_widths_that_change_between_frames(gpu_ctx, generator):
+    """the library owns the tiling and re-cuts it between frames.  Three frames of one context with three different
+    tilings (equal; very unequal incl. one-column tiles; the library's own rule applied to made-up tile times): every frame is the
+    single-context frame bit for bit, planes and lists, and atmrt_ctx_tile_columns reports what was used."""
+    ctx = generators.Context.multi([0] * 4)
+    try:
+        cfg, tiles = scene(generator, True, width=97, height=29)
+        W, H = cfg.params.width, cfg.params.height
+        want = run_gpu(gpu_ctx, cfg, tiles)
+        ctx.check(ctx.lib.atmrt_terrain_clear(ctx.handle))
+        gen = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, ctx))
+        images = [generators.image_planes(H, W, torch.device("cuda", 0)) for _ in range(4)]
+        equal = [g * W // 4 for g in range(5)]
+        out = (C.c_int32 * 5)()
+        ms = (C.c_double * 4)(10.0, 30.0, 5.0, 20.0)
+        assert ctx.lib.atmrt_tiles_rebalance(W, 4, (C.c_int32 * 5)(*equal), ms, out) == 0
+        for cols in (None, [0, 1, 2, 60, W], list(out), [0, 50, 51, 96, W], None):
+            ctx.set_tiling(cols)
+            gen.generate_image_device([pod for _, pod in images])
+            used = [ctx.tile_columns(i) for i in range(4)]
+            assert [u[0] for u in used] + [used[-1][1]] == (cols or equal)
+            for planes, _ in images:
+                check_image(planes, want)
+            for h in gen.image_hits_device(H, W):
+                check_lists(h, want)
+            # the host-consumer route cuts the same way
+            got = gen.generate()
+            if generator == "InterpolatingRectilinear":
+                got["ray_steps"] = want["ray_steps"]
+            assert_bitexact(got, want)
+    finally:
+        ctx.close()
+
+
+def test_tiles_are_recut_from_the_tile_times(gpu_ctx, monkeypatch):
+    """ATMRT_TILE_BALANCE=1 on sub-contexts of ONE device (where it is off by default: contended times mean nothing): whatever
+    tilings the noisy times produce from frame to frame, every frame is the single-context frame."""
+    monkeypatch.setenv("ATMRT_TILE_BALANCE", "1")
+    ctx = generators.Context.multi([0] * 3)
+    try:
+        cfg, tiles = scene("Rectilinear", True, width=301, height=64)
+        W, H = cfg.params.width, cfg.params.height
+        want = run_gpu(gpu_ctx, cfg, tiles)
+        ctx.check(ctx.lib.atmrt_terrain_clear(ctx.handle))
+        gen = generators.make_generator(generators.Params(cfg), generators.Terrain.from_tiles(tiles, ctx))
+        images = [generators.image_planes(H, W, torch.device("cuda", 0)) for _ in range(3)]
+        seen = set()
+        for frame in range(6):
+            gen.generate_image_device([pod for _, pod in images])
+            seen.add(tuple(ctx.tile_columns(i) for i in range(3)))
+            for planes, _ in images:
+                check_image(planes, want)
+            for h in gen.image_hits_device(H, W):
+                check_lists(h, want)
+            got = gen.generate()  # the host route re-cuts from its own times too
+            assert_bitexact(got, want)
+        print(f"tilings used over 6 + 6 frames: {sorted(seen)}")
+        assert all(t[0][0] == 0 and t[-1][1] == W and all(a[1] == b[0] and a[0] < a[1] for a, b in zip(t, t[1:])) for t in seen)
+    finally:
+        ctx.close()

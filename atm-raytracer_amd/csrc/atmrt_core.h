@@ -66,8 +66,13 @@ struct AtmSeg {
   // still bit-identical to the host.
   double safe_lo, safe_hi;
   int32_t cubic; // 1: a knot interval of a Spline temperature function
-  int32_t _pad;
+  // ATM_SEG_ISOTHERMAL: lapse == 0 (a scalar integer test in the kernels, where the double compare costs a VALU slot per stage).
+  // ATM_SEG_TIGHT (atm_certify): over [safe_lo, safe_hi) the three evaluation points of one ODE right-hand side (1 cm apart) have
+  // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-11 — so dm_div3 needs no
+  // vote on its seeds, 2 - Z seeds the reciprocal of Z and 1 - (n - 1) that of n (dm_div3_seeded, dm_div_seeded).
+  int32_t flags;
 };
+constexpr int32_t ATM_SEG_ISOTHERMAL = 1, ATM_SEG_TIGHT = 2;
 struct AtmTable {
   int32_t n;
   int32_t _pad;
@@ -391,6 +396,35 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
   return t.k_refr * ptmax * 2.0 <= 256.0;
 }
 
+// The extra bounds of a TIGHT segment over its certified interval [lo, hi] (Linear segments only; atm_interval_certified holds):
+//   (1) |lapse| eps / Tmin <= 2^-22: the temperatures at h, h -+ eps are within 2^-21 of one another after rounding;
+//   (2) the same for the compressibilities: |dZ| / Z <= 2 |dZ| with |dZ| <= d_pt ptmax amax + ptmax |lapse| eps (|a1| + 2 tm a2)
+//       + 2 d_pt ptmax^2 d, where d_pt = (g0 M / R + |lapse|) eps / Tmin bounds the relative change of p / T over eps
+//       (p is a power or an exponential of h with logarithmic derivative g0 M / (R T));
+//   (3) n - 1 = k_refr (p/T) / Z <= 2 k_refr ptmax <= 2^-11 and |1 - Z| <= ptmax amax + ptmax^2 d <= 2^-11: the squares are the
+//       seed errors of 1 - (n - 1) for 1/n and 2 - Z for 1/Z, 2^-22.
+// Every left side is evaluated with a margin of 1 % for the rounding of the bound itself.
+inline bool atm_interval_tight(const AtmTable& t, int k, double lo, double hi) {
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11, eps = 0.01, gmr = 9.80665 * 0.0289644 / 8.31432;
+  if (t.seg(k).cubic) return false;
+  const double t0 = atm_seg_temperature(t, k, lo), t1 = atm_seg_temperature(t, k, hi);
+  const double tmin = t0 < t1 ? t0 : t1, tmax = t0 < t1 ? t1 : t0;
+  if (!(tmin >= 1.0)) return false;
+  const double p0 = t.seg(k).pb * atm_pressure_ratio(t, k, lo), p1 = t.seg(k).pb * atm_pressure_ratio(t, k, hi);
+  const double pmax = p0 < p1 ? p1 : p0;
+  const double ptmax = pmax / tmin * 1.000001;
+  const double tm0 = dm_fabs(tmin - 273.15), tm1 = dm_fabs(tmax - 273.15), tm = tm0 > tm1 ? tm0 : tm1;
+  const double amax = a0 + tm * (dm_fabs(a1) + tm * a2);
+  const double al = dm_fabs(t.seg(k).lapse);
+  const double two21 = 4.76837158203125e-07, two11 = 4.8828125e-04; // 2^-21, 2^-11
+  if (!(1.01 * al * eps / tmin <= 0.5 * two21)) return false;
+  const double d_pt = 1.01 * (gmr + al) * eps / tmin;
+  const double dz = d_pt * ptmax * amax + ptmax * al * eps * (dm_fabs(a1) + 2.0 * tm * a2) + 2.0 * d_pt * ptmax * ptmax * d;
+  if (!(1.01 * 2.0 * dz <= two21)) return false;
+  if (!(1.01 * 2.0 * t.k_refr * ptmax <= two11)) return false;
+  return 1.01 * (ptmax * amax + ptmax * ptmax * d) <= two11;
+}
+
 // Fills safe_lo / safe_hi / alt_lo / alt_hi: for every segment an interval around an anchor altitude (sea level, the
 // segment's base, its middle or an end) that atm_interval_certified accepts, inside the global band of altitudes [alt_lo, alt_hi] =
 // [max(-100 km, 1 km - radius), 10 000 km].  Nothing is certified for a step outside 1 mm .. 1e8 m, a radius outside 1 km .. 1e12 m
@@ -399,6 +433,7 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
   for (int k = 0; k < t.n; k++) {
     t.seg(k).safe_lo = dm_inf();
     t.seg(k).safe_hi = -dm_inf();
+    t.seg(k).flags = !t.seg(k).cubic && t.seg(k).lapse == 0.0 ? ATM_SEG_ISOTHERMAL : 0;
   }
   t.alt_lo = dm_inf();
   t.alt_hi = -dm_inf();
@@ -451,6 +486,15 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
     }
     t.seg(k).safe_lo = lo;
     t.seg(k).safe_hi = hi;
+    // Tight where the whole certified interval is — or, failing that, its part above -1500 m when that part is: no ray marches
+    // below -1000 m (rectilinear.rs:178), and the lowest layer of a physical atmosphere is certified tens of kilometres further
+    // down than it is tight; below the cut the segment's evaluations take the IEEE operations.
+    if (atm_interval_tight(t, k, lo, hi)) {
+      t.seg(k).flags |= ATM_SEG_TIGHT;
+    } else if (lo < -1500.0 && hi > -1500.0 && atm_interval_tight(t, k, -1500.0, hi)) {
+      t.seg(k).safe_lo = -1500.0;
+      t.seg(k).flags |= ATM_SEG_TIGHT;
+    }
   }
 }
 
@@ -498,6 +542,23 @@ ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, doub
   const double z2 = 1.0 - pt2 * (a0 + c2 * (a1 + c2 * a2)) + pt2 * pt2 * d;
   double q0, q1, q2;
   dm_div3(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, &q0, &q1, &q2);
+  n0 = 1.0 + q0;
+  n1 = 1.0 + q1;
+  n2 = 1.0 + q2;
+}
+
+// the same on a TIGHT segment (AtmSeg::flags): no votes, the reciprocal of Z seeded by 2 - Z; q0 = n0 - 1 seeds the caller's 1 / n0
+ATMRT_HD void refr_from_tp3_tight(double k_refr, double t0, double t1, double t2, double p0, double p1, double p2, double& n0, double& n1,
+                                  double& n2, double& q0) {
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
+  double pt0, pt1, pt2;
+  dm_div3_seeded(p0, t0, p1, t1, p2, t2, 0, 0.0, &pt0, &pt1, &pt2);
+  const double c0 = t0 - 273.15, c1 = t1 - 273.15, c2 = t2 - 273.15;
+  const double z0 = 1.0 - pt0 * (a0 + c0 * (a1 + c0 * a2)) + pt0 * pt0 * d;
+  const double z1 = 1.0 - pt1 * (a0 + c1 * (a1 + c1 * a2)) + pt1 * pt1 * d;
+  const double z2 = 1.0 - pt2 * (a0 + c2 * (a1 + c2 * a2)) + pt2 * pt2 * d;
+  double q1, q2;
+  dm_div3_seeded(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, 1, 2.0 - z0, &q0, &q1, &q2);
   n0 = 1.0 + q0;
   n1 = 1.0 + q1;
   n2 = 1.0 + q2;
@@ -569,8 +630,8 @@ ATMRT_HD void pow3_in_range(double x0, double x1, double x2, double y, double& r
 // normal number and |expo log(T / tb)| (|expo (h - hb)| on an isothermal segment) is at most 645, so log and exp take their main
 // branches unasked — the values of refr_n_layer at the three points.
 template <bool CUBIC = true>
-ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, double rtb, double pb, double lapse, double c2, double c3,
-                            double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2) {
+ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double hb, double tb, double rtb, double pb, double lapse, double c2, double c3,
+                            double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2, double& q0) {
   if (CUBIC && cubic) {
     n0 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
     n1 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
@@ -579,14 +640,15 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, double hb, double tb, doub
   }
   const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
   double r0, r1, r2;
-  if (lapse != 0.0) {
+  if (!(flags & ATM_SEG_ISOTHERMAL)) {
     pow3_in_range(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
   } else {
     r0 = dm_exp_main(expo * (h0 - hb));
     r1 = dm_exp_main(expo * (h1 - hb));
     r2 = dm_exp_main(expo * (h2 - hb));
   }
-  refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
+  if (flags & ATM_SEG_TIGHT) refr_from_tp3_tight(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2, q0);
+  else refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
 }
 
 // Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).  IEEE operations throughout: the
@@ -671,9 +733,9 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   const AtmConstSeg ks = atm_const_seg(a, ku);
   if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
     const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
-    const int cubic = ks->cubic;
-    double n1, n2;
-    refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
+    const int cubic = ks->cubic, flags = ks->flags;
+    double n1, n2, q0;
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
     dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
     return true;
   }
@@ -1043,6 +1105,11 @@ ATMRT_HD double accel_rhs(bool spherical, double a, double b, double n, double d
   if (spherical) return a + div_sel<FAST>(2.0 * b * b, a) + div_sel<FAST>((a * a + b * b) * dn, n);
   return div_sel<FAST>((1.0 + b * b) * dn, n);
 }
+// the same on a TIGHT segment: q = n - 1 <= 2^-11, so 1 - q is a seed of 1 / n with error q^2 <= 2^-22 (dm_div_seeded)
+ATMRT_HD double accel_rhs_tight(bool spherical, double a, double b, double n, double q, double dn) {
+  if (spherical) return a + dm_div(2.0 * b * b, a) + dm_div_seeded((a * a + b * b) * dn, n, 1.0 - q);
+  return dm_div_seeded((1.0 + b * b) * dn, n, 1.0 - q);
+}
 // The generic right-hand side: per-lane layer search, IEEE operations — any atmosphere, any state.  On the GPU it runs for the few
 // steps in which a wavefront straddles a layer boundary, and all the time only in pathological atmospheres.  (Inline: as a call it
 // costs the hot path 2 % — live ranges split around the call site.)
@@ -1076,11 +1143,12 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   const AtmConstSeg ks = atm_const_seg(atm, ku);
   if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi && !(dm_fabs(b) > ACCEL_FAST_MAX_B))) {
     const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
-    const int cubic = ks->cubic;
-    double n, n1, n2;
-    refr_n_layer3<CUBIC>(k_refr, cubic, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2);
+    const int cubic = ks->cubic, flags = ks->flags;
+    double n, n1, n2, q0;
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
     const double dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
     fast = true;
+    if ((flags & ATM_SEG_TIGHT) && !(CUBIC && cubic)) return accel_rhs_tight(spherical, a, b, n, q0, dn);
     return accel_rhs<true>(spherical, a, b, n, dn);
   }
 #endif

@@ -1366,6 +1366,17 @@ __global__ void k_math_probe(int op, size_t n, const double* __restrict__ a, con
       dm_div3(x, y, x, y * 0.99999976158142090, x, y * 1.00000047683715820, &q0, &r0, &r1);
       break;
     }
+    case ATMRT_PROBE_DIV3_SEEDED: {
+      double q0;
+      dm_div3_seeded(x, y, x, y * 0.99999976158142090, x, y * 1.00000023841857910, 0, 0.0, &q0, &r0, &r1);
+      break;
+    }
+    case ATMRT_PROBE_DIV3_SEED_Z: {
+      double q1;
+      dm_div3_seeded(x, y, x, y * 0.99999976158142090, x, y * 1.00000023841857910, 1, 2.0 - y, &r0, &q1, &r1);
+      break;
+    }
+    case ATMRT_PROBE_DIV_SEED_N: r0 = dm_div_seeded(x, 1.0 + y, 1.0 - y); break;
     default: break;
   }
   out0[i] = r0;

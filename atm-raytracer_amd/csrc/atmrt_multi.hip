@@ -302,13 +302,21 @@ atmrt_ctx* multi_child(atmrt_ctx* parent, int i) { return parent->multi->kids[(s
 
 int multi_forward(atmrt_ctx* parent, const std::function<int(atmrt_ctx*)>& fn) {
   MultiGroup* g = parent->multi;
-  const int rc = g->run([&](atmrt_ctx* k, int) { return fn(k); });
-  if (rc)
-    for (size_t i = 0; i < g->kids.size(); i++)
-      if (g->rc[i]) {
-        parent->error = "device " + std::to_string(g->devices[i]) + ": " + g->kids[i]->error;
+  int rc = g->run([&](atmrt_ctx* k, int) { return fn(k); });
+  if (rc) {
+    // the message of the device that failed FIRST-HAND, not of one that was released from a barrier because of it
+    int who = -1;
+    for (size_t i = 0; i < g->kids.size(); i++) {
+      if (!g->rc[i]) continue;
+      if (who < 0) who = (int)i;
+      if (g->kids[i]->error.find("another device of the context failed") == std::string::npos) {
+        who = (int)i;
         break;
       }
+    }
+    rc = g->rc[(size_t)who];
+    parent->error = "device " + std::to_string(g->devices[(size_t)who]) + " (tile " + std::to_string(who) + "): " + g->kids[(size_t)who]->error;
+  }
   return rc;
 }
 

@@ -60,6 +60,38 @@ DM_FN double dm_to_degrees(double rad) { return rad * DM_DEG_PER_RAD; }
 /* Fused multiply-add (one rounding) and exact scaling by 2^e.  detmath's own polynomials and reductions use them on both
  * sides; the formulas restated from the reference never do (Rust does not contract a*b+c). */
 #define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+/* The same FMA with the PLACE of its constants spelled out for gfx950.  A VALU instruction of gfx9 reads at most one scalar
+ * operand and no 64-bit literal, and hipcc's choice for `fma(r, K1, K0)` / `fma(r, q, K)` is the two-address v_fmac with the constant
+ * addend copied into a VGPR pair first: 15 v_mov per RK4 stage in the marching kernels (profiles/r03: 228 "other" lane-instructions
+ * per ray-step).  Written as VOP3 v_fma_f64 with the constant in an SGPR pair (two s_mov: scalar unit, not a VALU slot) the copies
+ * disappear.  Same operation, same rounding: the value is DM_FMA's on both sides.
+ *   DM_FMA_VVS(a, b, K)      a * b + K      K: scalar constant
+ *   DM_FMA_VSV(a, K, v)      a * K + v      K: scalar constant, v: a value that lives in a VGPR (possibly itself a constant)
+ *   DM_FNMA_VVV(a, b, c)     c - a * b      the residual of a Newton step: the negation is a source modifier, not a v_xor + v_mov */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double dm_fma_vvs_(double a, double b, double k) {
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+}
+static __device__ __forceinline__ double dm_fma_vsv_(double a, double k, double v) {
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(v));
+  return d;
+}
+static __device__ __forceinline__ double dm_fnma_vvv_(double a, double b, double c) {
+  double d;
+  __asm__("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+#define DM_FMA_VVS(a, b, k) dm_fma_vvs_((a), (b), (k))
+#define DM_FMA_VSV(a, k, v) dm_fma_vsv_((a), (k), (v))
+#define DM_FNMA_VVV(a, b, c) dm_fnma_vvv_((a), (b), (c))
+#else
+#define DM_FMA_VVS(a, b, k) DM_FMA((a), (b), (k))
+#define DM_FMA_VSV(a, k, v) DM_FMA((a), (k), (v))
+#define DM_FNMA_VVV(a, b, c) DM_FMA(-(a), (b), (c))
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DM_SCALBN(y, e) __builtin_ldexp((y), (e))
 #else
@@ -81,11 +113,29 @@ DM_FN double dm_div(double a, double b) {
   e = __builtin_fma(-b, r, 1.0);
   r = __builtin_fma(r, e, r);
   double q = a * r;
-  e = __builtin_fma(-b, q, a);
+  e = DM_FNMA_VVV(b, q, a);
   return __builtin_fma(e, r, q);
 }
 #else
 DM_FN double dm_div(double a, double b) { return a / b; }
+#endif
+
+/* a / b from a SEED r0 of 1/b with |1 - b r0| <= 2^-20 — a bound the CALLER holds (a certificate, atm_certify): two Newton steps take
+ * the seed to 2^-80 before rounding, the class of reciprocal dm_div's own two steps from v_rcp_f64 produce, and the quotient
+ * correction is dm_div's.  7 full-rate instructions in place of the quarter-rate v_rcp_f64 + 7.  Host: the IEEE division.
+ * Same operand range as dm_div. */
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN double dm_div_seeded(double a, double b, double r0) {
+  double e = __builtin_fma(-b, r0, 1.0);
+  double r = __builtin_fma(r0, e, r0);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = a * r;
+  e = DM_FNMA_VVV(b, q, a);
+  return __builtin_fma(e, r, q);
+}
+#else
+DM_FN double dm_div_seeded(double a, double b, double r0) { (void)r0; return a / b; }
 #endif
 
 /* Three divisions a_i / b_i whose divisors are (expected to be) within 2^-20 of one another — the temperatures, and the
@@ -94,7 +144,10 @@ DM_FN double dm_div(double a, double b) { return a / b; }
  * seed error |1 - b_i r_0| <= 2^-20 two Newton steps leave 2^-80 before rounding, the same class of reciprocal dm_div's own two
  * steps from v_rcp_f64 produce, and the quotient correction is dm_div's.  That saves the two quarter-rate v_rcp_f64 (the guard costs
  * what the two instructions save).  The guard is a wave vote; lanes that fail it (or hold NaN) send the whole wavefront through
- * dm_div.  Same operand range as dm_div.  tests/test_gpu_detmath.py checks the sequence against IEEE division like dm_div. */
+ * dm_div.  Same operand range as dm_div.  tests/test_gpu_detmath.py checks the sequence against IEEE division like dm_div.
+ * dm_div3_seeded: the same for call sites that HOLD the bound |1 - b_i / b_0| <= 2^-21 as a certificate (atm_certify's `tight`
+ * segments) — no vote — and, optionally, a seed r0 for b_0's own reciprocal (have_seed: |1 - b_0 r0| <= 2^-20, likewise
+ * certified) in place of its v_rcp_f64. */
 #if defined(__HIP_DEVICE_COMPILE__)
 DM_FN void dm_div3(double a0, double b0, double a1, double b1, double a2, double b2, double* q0, double* q1, double* q2) {
   double r = __builtin_amdgcn_rcp(b0);
@@ -103,7 +156,7 @@ DM_FN void dm_div3(double a0, double b0, double a1, double b1, double a2, double
   e = __builtin_fma(-b0, r, 1.0);
   r = __builtin_fma(r, e, r);
   double q = a0 * r;
-  e = __builtin_fma(-b0, q, a0);
+  e = DM_FNMA_VVV(b0, q, a0);
   *q0 = __builtin_fma(e, r, q);
   double e1 = __builtin_fma(-b1, r, 1.0), e2 = __builtin_fma(-b2, r, 1.0);
   double m = __builtin_fmax(__builtin_fabs(e1), __builtin_fabs(e2));
@@ -112,21 +165,59 @@ DM_FN void dm_div3(double a0, double b0, double a1, double b1, double a2, double
     e1 = __builtin_fma(-b1, r1, 1.0);
     r1 = __builtin_fma(r1, e1, r1);
     q = a1 * r1;
-    e1 = __builtin_fma(-b1, q, a1);
+    e1 = DM_FNMA_VVV(b1, q, a1);
     *q1 = __builtin_fma(e1, r1, q);
     double r2 = __builtin_fma(r, e2, r);
     e2 = __builtin_fma(-b2, r2, 1.0);
     r2 = __builtin_fma(r2, e2, r2);
     q = a2 * r2;
-    e2 = __builtin_fma(-b2, q, a2);
+    e2 = DM_FNMA_VVV(b2, q, a2);
     *q2 = __builtin_fma(e2, r2, q);
   } else {
     *q1 = dm_div(a1, b1);
     *q2 = dm_div(a2, b2);
   }
 }
+DM_FN void dm_div3_seeded(double a0, double b0, double a1, double b1, double a2, double b2, int have_seed, double r0, double* q0, double* q1,
+                          double* q2) {
+  double r, e;
+  if (have_seed) { /* compile-time at every call site */
+    e = __builtin_fma(-b0, r0, 1.0);
+    r = __builtin_fma(r0, e, r0);
+  } else {
+    r = __builtin_amdgcn_rcp(b0);
+    e = __builtin_fma(-b0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+  }
+  e = __builtin_fma(-b0, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = a0 * r;
+  e = DM_FNMA_VVV(b0, q, a0);
+  *q0 = __builtin_fma(e, r, q);
+  double e1 = __builtin_fma(-b1, r, 1.0), e2 = __builtin_fma(-b2, r, 1.0);
+  double r1 = __builtin_fma(r, e1, r);
+  e1 = __builtin_fma(-b1, r1, 1.0);
+  r1 = __builtin_fma(r1, e1, r1);
+  q = a1 * r1;
+  e1 = DM_FNMA_VVV(b1, q, a1);
+  *q1 = __builtin_fma(e1, r1, q);
+  double r2 = __builtin_fma(r, e2, r);
+  e2 = __builtin_fma(-b2, r2, 1.0);
+  r2 = __builtin_fma(r2, e2, r2);
+  q = a2 * r2;
+  e2 = DM_FNMA_VVV(b2, q, a2);
+  *q2 = __builtin_fma(e2, r2, q);
+}
 #else
 DM_FN void dm_div3(double a0, double b0, double a1, double b1, double a2, double b2, double* q0, double* q1, double* q2) {
+  *q0 = a0 / b0;
+  *q1 = a1 / b1;
+  *q2 = a2 / b2;
+}
+DM_FN void dm_div3_seeded(double a0, double b0, double a1, double b1, double a2, double b2, int have_seed, double r0, double* q0, double* q1,
+                          double* q2) {
+  (void)have_seed;
+  (void)r0;
   *q0 = a0 / b0;
   *q1 = a1 / b1;
   *q2 = a2 / b2;
@@ -438,8 +529,8 @@ DM_FN double dm_exp_main(double x) { /* |x| <= 700 */
   t = DM_EXP_ROW(ki & 127);
   e = ki >> 7;
   r2 = r * r;
-  q = DM_FMA(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
-  q = DM_FMA(r, q, 1.66666666666666667e-01);
+  q = DM_FMA_VSV(r, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  q = DM_FMA_VVS(r, q, 1.66666666666666667e-01);
   q = DM_FMA(r, q, 0.5);
   p = DM_FMA(r2, q, r);
   s = DM_FMA(t[0], p, t[1]);
@@ -494,10 +585,10 @@ DM_FN double dm_log_core_pow(double x) {
   double w = DM_FMA(kd, DM_LN2_HI, t[1]);
   double lo = DM_FMA(kd, DM_LN2_LO, t[2]);
   double r2 = r * r, p;
-  p = DM_FMA(r, 1.42857142857142857e-01, -1.66666666666666667e-01);
-  p = DM_FMA(r, p, 0.2);
-  p = DM_FMA(r, p, -0.25);
-  p = DM_FMA(r, p, 3.33333333333333333e-01);
+  p = DM_FMA_VSV(r, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  p = DM_FMA_VVS(r, p, 0.2);
+  p = DM_FMA_VVS(r, p, -0.25);
+  p = DM_FMA_VVS(r, p, 3.33333333333333333e-01);
   p = DM_FMA(r, p, -0.5);
   return w + (DM_FMA(r2, p, r) + lo);
 }

@@ -23,3 +23,18 @@ void t_div3(const double* a, const double* b, double* y0, double* y1, size_t n) 
     dm_div3(a[i], b[i], a[i], b[i] * 0.99999976158142090, a[i], b[i] * 1.00000047683715820, &q0, &y0[i], &y1[i]);
   }
 }
+void t_div3_seeded(const double* a, const double* b, double* y0, double* y1, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    double q0;
+    dm_div3_seeded(a[i], b[i], a[i], b[i] * 0.99999976158142090, a[i], b[i] * 1.00000023841857910, 0, 0.0, &q0, &y0[i], &y1[i]);
+  }
+}
+void t_div3_seed_z(const double* a, const double* b, double* y0, double* y1, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    double q1;
+    dm_div3_seeded(a[i], b[i], a[i], b[i] * 0.99999976158142090, a[i], b[i] * 1.00000023841857910, 1, 2.0 - b[i], &y0[i], &q1, &y1[i]);
+  }
+}
+void t_div_seed_n(const double* a, const double* b, double* y, size_t n) {
+  for (size_t i = 0; i < n; i++) y[i] = dm_div_seeded(a[i], 1.0 + b[i], 1.0 - b[i]);
+}

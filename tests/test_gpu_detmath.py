@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 N = 10_000_000
 OPS = dict(DIV=0, DIV_R=1, SQRT_INRANGE=2, EXP=3, LOG=4, POW=5, SINCOS=6, ASIN=7, ATAN2=8, IEEE_DIV=9, IEEE_SQRT=10, ATAN=11,
-           TAN=12, POW3=13, DIV3=14)
+           TAN=12, POW3=13, DIV3=14, DIV3_SEEDED=15, DIV3_SEED_Z=16, DIV_SEED_N=17)
 
 
 @pytest.fixture(scope="module")
@@ -137,6 +137,46 @@ def test_dm_div3_seeded_reciprocals_give_ieee_quotients(gpu_ctx, host):
         q1, q2 = gpu(gpu_ctx, "DIV3", p, b2, two=True)
         ok = np.isfinite(b2)
         same(q1[ok], (p / (b2 * 0.99999976158142090))[ok], "dm_div3 beside NaN lanes")
+
+
+def test_seeded_divisions_of_tight_segments_give_ieee_quotients(gpu_ctx, host):
+    """Round 4: on a TIGHT atmosphere segment (atm_certify) the bounds dm_div3 votes on are certified, so its seeded reciprocals
+    run without the vote (dm_div3_seeded), the reciprocal of Z = 1 - small is seeded by 2 - Z and that of n = 1 + q by 1 - q
+    (dm_div_seeded) in place of v_rcp_f64.  Every quotient must be the IEEE quotient: 1e7 operands per site from the call sites'
+    own populations, at and beyond the certified bounds' edges (|1 - Z|, q up to 2^-11 exactly; divisors 2^-22 apart)."""
+    rng = np.random.default_rng(41)
+    lo, hi = 0.99999976158142090, 1.00000023841857910  # 1 -+ 2^-22
+    # p / T: no seed for the centre, no vote for the outer two
+    p = rng.uniform(100.0, 115000.0, N)
+    t = rng.uniform(150.0, 330.0, N)
+    q1, q2 = gpu(gpu_ctx, "DIV3_SEEDED", p, t, two=True)
+    same(q1, p / (t * lo), "p / T below")
+    same(q2, p / (t * hi), "p / T above")
+    h1, h2 = cpu(host, "div3_seeded", p, t, outs=2)
+    same(q1, h1, "dm_div3_seeded vs host")
+    same(q2, h2, "dm_div3_seeded vs host")
+    a, b = in_range_pairs(rng, N, lim=480)
+    with np.errstate(all="ignore"):
+        q1, q2 = gpu(gpu_ctx, "DIV3_SEEDED", a, b, two=True)
+        same(q1, a / (b * lo), "dm_div3_seeded over the exponent range, below")
+        same(q2, a / (b * hi), "dm_div3_seeded over the exponent range, above")
+    # K (p / T) / Z with Z = 1 - small: centre seeded by 2 - Z
+    kz = rng.uniform(1e-7, 3e-4, N)
+    z = 1.0 - rng.uniform(-4.8828125e-04, 4.8828125e-04, N)
+    z[: N // 8] = 1.0 - rng.choice([4.8828125e-04, -4.8828125e-04, 0.0, 2.0 ** -30, 4.0e-4], N // 8)
+    q0, q2 = gpu(gpu_ctx, "DIV3_SEED_Z", kz, z, two=True)
+    same(q0, kz / z, "K pt / Z, centre seeded by 2 - Z")
+    same(q2, kz / (z * hi), "K pt / Z above")
+    h0, h2 = cpu(host, "div3_seed_z", kz, z, outs=2)
+    same(q0, h0, "dm_div3_seeded(seed) vs host")
+    same(q2, h2, "dm_div3_seeded(seed) vs host")
+    # X / n with n = 1 + q, seeded by 1 - q: the numerators of the ODE's right-hand side span many binades
+    q = rng.uniform(0.0, 4.8828125e-04, N)
+    q[: N // 8] = rng.choice([4.8828125e-04, 0.0, 2.0 ** -40, 2.8e-4], N // 8)
+    x = mantissa(rng, N) * 2.0 ** rng.integers(-60, 60, N)
+    got = gpu(gpu_ctx, "DIV_SEED_N", x, q)
+    same(got, x / (1.0 + q), "X / n seeded by 1 - (n - 1)")
+    same(got, cpu(host, "div_seed_n", x, q), "dm_div_seeded vs host")
 
 
 def test_dm_sqrt_inrange_is_ieee_sqrt_in_range(gpu_ctx, host):

@@ -68,7 +68,7 @@ struct AtmSeg {
   int32_t cubic; // 1: a knot interval of a Spline temperature function
   // ATM_SEG_ISOTHERMAL: lapse == 0 (a scalar integer test in the kernels, where the double compare costs a VALU slot per stage).
   // ATM_SEG_TIGHT (atm_certify): over [safe_lo, safe_hi) the three evaluation points of one ODE right-hand side (1 cm apart) have
-  // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-11 — so dm_div3 needs no
+  // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-10.5 — so dm_div3 needs no
   // vote on its seeds, 2 - Z seeds the reciprocal of Z and 1 - (n - 1) that of n (dm_div3_seeded, dm_div_seeded).
   int32_t flags;
 };
@@ -397,32 +397,47 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
 }
 
 // The extra bounds of a TIGHT segment over its certified interval [lo, hi] (Linear segments only; atm_interval_certified holds):
-//   (1) |lapse| eps / Tmin <= 2^-22: the temperatures at h, h -+ eps are within 2^-21 of one another after rounding;
+//   (1) |lapse| eps / Tmin <= 2^-21: the temperatures at h, h -+ eps are within 2^-21 (1 + 2^-40) of one another after rounding,
+//       half of what dm_div3's seeds tolerate (2^-20);
 //   (2) the same for the compressibilities: |dZ| / Z <= 2 |dZ| with |dZ| <= d_pt ptmax amax + ptmax |lapse| eps (|a1| + 2 tm a2)
 //       + 2 d_pt ptmax^2 d, where d_pt = (g0 M / R + |lapse|) eps / Tmin bounds the relative change of p / T over eps
 //       (p is a power or an exponential of h with logarithmic derivative g0 M / (R T));
-//   (3) n - 1 = k_refr (p/T) / Z <= 2 k_refr ptmax <= 2^-11 and |1 - Z| <= ptmax amax + ptmax^2 d <= 2^-11: the squares are the
-//       seed errors of 1 - (n - 1) for 1/n and 2 - Z for 1/Z, 2^-22.
+//   (3) |1 - Z| <= ptmax amax + ptmax^2 d <= 2^-10.5 and n - 1 = k_refr (p/T) / Z <= k_refr ptmax / (1 - 2^-10.5) <= 2^-10.5: the
+//       squares are the seed errors of 2 - Z for 1/Z and of 1 - (n - 1) for 1/n, 2^-21 — half of what the seeded divisions are
+//       tested for (2^-20).  (Standard air at sea level: |1 - Z| = 4.1e-4, n - 1 = 2.8e-4; 2^-10.5 = 6.9e-4.)
 // Every left side is evaluated with a margin of 1 % for the rounding of the bound itself.
 inline bool atm_interval_tight(const AtmTable& t, int k, double lo, double hi) {
   const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11, eps = 0.01, gmr = 9.80665 * 0.0289644 / 8.31432;
-  if (t.seg(k).cubic) return false;
-  const double t0 = atm_seg_temperature(t, k, lo), t1 = atm_seg_temperature(t, k, hi);
-  const double tmin = t0 < t1 ? t0 : t1, tmax = t0 < t1 ? t1 : t0;
-  if (!(tmin >= 1.0)) return false;
-  const double p0 = t.seg(k).pb * atm_pressure_ratio(t, k, lo), p1 = t.seg(k).pb * atm_pressure_ratio(t, k, hi);
-  const double pmax = p0 < p1 ? p1 : p0;
-  const double ptmax = pmax / tmin * 1.000001;
-  const double tm0 = dm_fabs(tmin - 273.15), tm1 = dm_fabs(tmax - 273.15), tm = tm0 > tm1 ? tm0 : tm1;
-  const double amax = a0 + tm * (dm_fabs(a1) + tm * a2);
+  const double two21 = 4.76837158203125e-07, seed = 6.9053396600248786e-04; // 2^-21, 2^-10.5
+  if (t.seg(k).cubic || !(lo < hi)) return false;
   const double al = dm_fabs(t.seg(k).lapse);
-  const double two21 = 4.76837158203125e-07, two11 = 4.8828125e-04; // 2^-21, 2^-11
-  if (!(1.01 * al * eps / tmin <= 0.5 * two21)) return false;
-  const double d_pt = 1.01 * (gmr + al) * eps / tmin;
-  const double dz = d_pt * ptmax * amax + ptmax * al * eps * (dm_fabs(a1) + 2.0 * tm * a2) + 2.0 * d_pt * ptmax * ptmax * d;
-  if (!(1.01 * 2.0 * dz <= two21)) return false;
-  if (!(1.01 * 2.0 * t.k_refr * ptmax <= two11)) return false;
-  return 1.01 * (ptmax * amax + ptmax * ptmax * d) <= two11;
+  // In pieces: over a Linear segment T is monotone in h and so is p / T (a power of T, or an exponential of h), so the end points of
+  // a piece bound both; a(c) = a0 + c (a1 + c a2) is a convex parabola in c = T - 273.15, so |a| is largest at an end point or at
+  // its vertex.  The quantities are smooth: 64 pieces leave the bounds within a few per cent of the true maxima.
+  const int pieces = 64;
+  const double cv = -a1 / (2.0 * a2), av = dm_fabs(a0 + cv * (a1 + cv * a2)); // the vertex of a(c) and |a| there
+  double h0 = lo, t0 = atm_seg_temperature(t, k, lo), pt0 = t.seg(k).pb * atm_pressure_ratio(t, k, lo) / t0;
+  for (int i = 1; i <= pieces; i++) {
+    const double h1 = i == pieces ? hi : lo + (hi - lo) * (double)i / (double)pieces;
+    const double t1 = atm_seg_temperature(t, k, h1), pt1 = t.seg(k).pb * atm_pressure_ratio(t, k, h1) / t1;
+    const double tmin = t0 < t1 ? t0 : t1, tmax = t0 < t1 ? t1 : t0;
+    if (!(tmin >= 1.0) || !(pt0 > 0.0) || !(pt1 > 0.0)) return false;
+    const double ptmax = (pt0 > pt1 ? pt0 : pt1) * 1.000001;
+    const double c0 = t0 - 273.15, c1 = t1 - 273.15, cmin = tmin - 273.15, cmax = tmax - 273.15;
+    const double e0 = dm_fabs(a0 + c0 * (a1 + c0 * a2)), e1 = dm_fabs(a0 + c1 * (a1 + c1 * a2));
+    double amax = e0 > e1 ? e0 : e1;
+    if (cmin <= cv && cv <= cmax && av > amax) amax = av;
+    const double tm = dm_fabs(cmin) > dm_fabs(cmax) ? dm_fabs(cmin) : dm_fabs(cmax);
+    if (!(1.01 * al * eps / tmin <= two21)) return false;                                          // (1)
+    const double d_pt = 1.01 * (gmr + al) * eps / tmin;
+    const double dz = d_pt * ptmax * amax + ptmax * al * eps * (dm_fabs(a1) + 2.0 * tm * a2) + 2.0 * d_pt * ptmax * ptmax * d;
+    if (!(1.01 * 2.0 * dz <= two21)) return false;                                                 // (2)
+    if (!(1.01 * (ptmax * amax + ptmax * ptmax * d) <= seed)) return false;                        // (3) |1 - Z|
+    if (!(1.01 * t.k_refr * ptmax / (1.0 - seed) <= seed)) return false;                           // (3) n - 1 = k (p/T) / Z, Z >= 1 - seed
+    h0 = h1, t0 = t1, pt0 = pt1;
+  }
+  (void)h0;
+  return true;
 }
 
 // Fills safe_lo / safe_hi / alt_lo / alt_hi: for every segment an interval around an anchor altitude (sea level, the
@@ -486,13 +501,17 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
     }
     t.seg(k).safe_lo = lo;
     t.seg(k).safe_hi = hi;
-    // Tight where the whole certified interval is — or, failing that, its part above -1500 m when that part is: no ray marches
-    // below -1000 m (rectilinear.rs:178), and the lowest layer of a physical atmosphere is certified tens of kilometres further
-    // down than it is tight; below the cut the segment's evaluations take the IEEE operations.
+    // Tight where the whole certified interval is.  Failing that, where its part between -1500 m and 100 km is — no ray marches
+    // below -1000 m (rectilinear.rs:178) and the layers of a physical atmosphere are certified tens of kilometres further down
+    // (and up: to where an extrapolated temperature reaches 1 K) than they are tight — keeping whatever of the rest is tight too;
+    // outside the cut the segment's evaluations take the IEEE operations.
+    const double cut_lo = lo > -1500.0 ? lo : -1500.0, cut_hi = hi < 1.0e5 ? hi : 1.0e5;
     if (atm_interval_tight(t, k, lo, hi)) {
       t.seg(k).flags |= ATM_SEG_TIGHT;
-    } else if (lo < -1500.0 && hi > -1500.0 && atm_interval_tight(t, k, -1500.0, hi)) {
-      t.seg(k).safe_lo = -1500.0;
+    } else if (cut_lo < cut_hi && atm_interval_tight(t, k, cut_lo, cut_hi)) {
+      if (atm_interval_tight(t, k, lo, cut_hi)) t.seg(k).safe_hi = cut_hi;
+      else if (atm_interval_tight(t, k, cut_lo, hi)) t.seg(k).safe_lo = cut_lo;
+      else t.seg(k).safe_lo = cut_lo, t.seg(k).safe_hi = cut_hi;
       t.seg(k).flags |= ATM_SEG_TIGHT;
     }
   }
@@ -1105,7 +1124,7 @@ ATMRT_HD double accel_rhs(bool spherical, double a, double b, double n, double d
   if (spherical) return a + div_sel<FAST>(2.0 * b * b, a) + div_sel<FAST>((a * a + b * b) * dn, n);
   return div_sel<FAST>((1.0 + b * b) * dn, n);
 }
-// the same on a TIGHT segment: q = n - 1 <= 2^-11, so 1 - q is a seed of 1 / n with error q^2 <= 2^-22 (dm_div_seeded)
+// the same on a TIGHT segment: q = n - 1 <= 2^-10.5, so 1 - q is a seed of 1 / n with error q^2 <= 2^-21 (dm_div_seeded)
 ATMRT_HD double accel_rhs_tight(bool spherical, double a, double b, double n, double q, double dn) {
   if (spherical) return a + dm_div(2.0 * b * b, a) + dm_div_seeded((a * a + b * b) * dn, n, 1.0 - q);
   return dm_div_seeded((1.0 + b * b) * dn, n, 1.0 - q);

@@ -478,9 +478,9 @@ typedef enum atmrt_math_probe_op {
                                    from b's; the centre quotient a / b is ATMRT_PROBE_DIV's */
   ATMRT_PROBE_DIV3_SEEDED = 15, /* dm_div3_seeded without a seed for b (the p / T site of a tight atmosphere segment): the DIV3 outputs
                                    for divisors b (1 -+ 2^-22), no vote */
-  ATMRT_PROBE_DIV3_SEED_Z = 16, /* dm_div3_seeded with b = Z close to 1 (|1 - Z| <= 2^-11) and 2 - Z as the seed of its reciprocal:
+  ATMRT_PROBE_DIV3_SEED_Z = 16, /* dm_div3_seeded with b = Z close to 1 (|1 - Z| <= 2^-10.5) and 2 - Z as the seed of its reciprocal:
                                    out0 = a / b, out1 = a / (b (1 + 2^-22)) */
-  ATMRT_PROBE_DIV_SEED_N = 17   /* dm_div_seeded(a, 1 + b, 1 - b) for 0 <= b <= 2^-11: a / n with n = 1 + (n - 1) */
+  ATMRT_PROBE_DIV_SEED_N = 17   /* dm_div_seeded(a, 1 + b, 1 - b) for 0 <= b <= 2^-10.5: a / n with n = 1 + (n - 1) */
 } atmrt_math_probe_op;
 int atmrt_math_probe(atmrt_ctx* ctx, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1);
 

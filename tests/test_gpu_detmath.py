@@ -143,7 +143,8 @@ def test_seeded_divisions_of_tight_segments_give_ieee_quotients(gpu_ctx, host):
     """Round 4: on a TIGHT atmosphere segment (atm_certify) the bounds dm_div3 votes on are certified, so its seeded reciprocals
     run without the vote (dm_div3_seeded), the reciprocal of Z = 1 - small is seeded by 2 - Z and that of n = 1 + q by 1 - q
     (dm_div_seeded) in place of v_rcp_f64.  Every quotient must be the IEEE quotient: 1e7 operands per site from the call sites'
-    own populations, at and beyond the certified bounds' edges (|1 - Z|, q up to 2^-11 exactly; divisors 2^-22 apart)."""
+    own populations, up to the certified bounds' edges (|1 - Z|, q up to 2^-10.5 exactly; divisors 2^-22 apart) and, for the
+    seeds, beyond them (2^-10: the seed error the unseeded dm_div3 already votes for)."""
     rng = np.random.default_rng(41)
     lo, hi = 0.99999976158142090, 1.00000023841857910  # 1 -+ 2^-22
     # p / T: no seed for the centre, no vote for the outer two
@@ -162,8 +163,8 @@ def test_seeded_divisions_of_tight_segments_give_ieee_quotients(gpu_ctx, host):
         same(q2, a / (b * hi), "dm_div3_seeded over the exponent range, above")
     # K (p / T) / Z with Z = 1 - small: centre seeded by 2 - Z
     kz = rng.uniform(1e-7, 3e-4, N)
-    z = 1.0 - rng.uniform(-4.8828125e-04, 4.8828125e-04, N)
-    z[: N // 8] = 1.0 - rng.choice([4.8828125e-04, -4.8828125e-04, 0.0, 2.0 ** -30, 4.0e-4], N // 8)
+    z = 1.0 - rng.uniform(-6.9053396600248786e-04, 6.9053396600248786e-04, N)
+    z[: N // 8] = 1.0 - rng.choice([6.9053396600248786e-04, -6.9053396600248786e-04, 0.0, 2.0 ** -30, 4.0e-4, 2.0 ** -10, -(2.0 ** -10)], N // 8)
     q0, q2 = gpu(gpu_ctx, "DIV3_SEED_Z", kz, z, two=True)
     same(q0, kz / z, "K pt / Z, centre seeded by 2 - Z")
     same(q2, kz / (z * hi), "K pt / Z above")
@@ -171,8 +172,8 @@ def test_seeded_divisions_of_tight_segments_give_ieee_quotients(gpu_ctx, host):
     same(q0, h0, "dm_div3_seeded(seed) vs host")
     same(q2, h2, "dm_div3_seeded(seed) vs host")
     # X / n with n = 1 + q, seeded by 1 - q: the numerators of the ODE's right-hand side span many binades
-    q = rng.uniform(0.0, 4.8828125e-04, N)
-    q[: N // 8] = rng.choice([4.8828125e-04, 0.0, 2.0 ** -40, 2.8e-4], N // 8)
+    q = rng.uniform(0.0, 6.9053396600248786e-04, N)
+    q[: N // 8] = rng.choice([6.9053396600248786e-04, 0.0, 2.0 ** -40, 2.8e-4, 2.0 ** -10], N // 8)
     x = mantissa(rng, N) * 2.0 ** rng.integers(-60, 60, N)
     got = gpu(gpu_ctx, "DIV_SEED_N", x, q)
     same(got, x / (1.0 + q), "X / n seeded by 1 - (n - 1)")

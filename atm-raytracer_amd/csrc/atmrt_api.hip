@@ -514,6 +514,8 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   const atmrt_params_t& p = c->params;
   if (atm_compile(c->atm_def.pod, p.wavelength, c->atm)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere");
   atm_certify(c->atm.table(), c->earth.spherical != 0, c->earth.shape_radius, p.simulation_step);
+  if (getenv("ATMRT_NO_TIGHT")) // experiments: the voting path of dm_div3 on every segment (same bits, tests/test_gpu_march_variants.py)
+    for (int k = 0; k < c->atm.table().n; k++) c->atm.table().seg(k).flags &= ~ATM_SEG_TIGHT;
   pinhole_init(p, c->pinhole);
   if (c->xs_dirty) {
     // distance table by repeated addition, exactly like `distance += step` (utils.rs:191-196) and the
@@ -752,16 +754,12 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (general) {
-    // Rectilinear with scene objects: the lean march first (it leaves the rays that can meet an object to the general tracer and
-    // lists them), then the tracer over that list
-    HIP_TRY(c, c->d_object_rays.reserve((size_t)f.wl * f.h * sizeof(uint32_t)));
+    // Rectilinear with scene objects: the lean march, which hands the rays that can meet an object to the general tracer at the step
+    // that flags them, and the tracer beside it on the second stream, consuming that queue (launch_rect_trace_count)
+    HIP_TRY(c, c->d_object_rays.reserve(((size_t)f.wl * f.h + 64) * sizeof(uint32_t)));
     ws.object_rays = c->d_object_rays.as<uint32_t>();
     HIP_TRY(c, hipEventRecord(ev[4], s));
-    launch_trace_count(f, ws, dense, s);
-    uint64_t cnt[N_COUNTERS] = {};
-    HIP_TRY(c, hipMemcpyAsync(cnt, ws.counters, sizeof cnt, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    launch_rect_trace_objects(f, ws, dense, cnt[11], s);
+    launch_trace_count(f, ws, dense, s, c->stream2, c->ev_fork, c->ev_join);
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (fast) {
@@ -1018,6 +1016,8 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     c->timings = t;
   }
   (void)fast;
+  if (counters[12] && f.n_objects && f.p.generator == ATMRT_GEN_RECTILINEAR)
+    return c->fail(ATMRT_ERR_HIP, "the general tracer waited 30 s for the lean march beside it to end: the two streams did not run concurrently");
   if (counters[12])
     return c->fail(ATMRT_ERR_HIP, "the time-sliced march left %llu of its ray groups unfinished", (unsigned long long)counters[12] - 1);
   c->stats.unlisted_rays = counters[4];

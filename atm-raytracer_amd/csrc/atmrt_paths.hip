@@ -161,7 +161,13 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   AtmLayerCache cache; // the hinted layer's parameters, wave-uniform, read again only when the layer changes
   for (int i = i_begin; i < i_last; i++) {
     bool tame;
+    // A row that has finished takes part in every shuffle but does not move on: it repeats its last step.  (Left to run, a ray that
+    // ended below -1000 m keeps descending, leaves the certified part of the lowest layer a few steps later — and from then on every
+    // step of its whole wavefront fails the vote and is repeated by the serial stepper.)
+    const Stepper s_before = s;
+    const bool was_done = done;
     RayState st = rk4.next(s, cache, sph, radius, straight, step, tame);
+    if (was_done) s = s_before;
     if (straight) tame = __all(calc_dist_in_band(*f.atm, ph) && calc_dist_in_band(*f.atm, st.h));
     path_length += calc_dist(sph, radius, px, ph, st.x, st.h, tame);
     if (!done) {
@@ -175,8 +181,10 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
         n_final = n;
       }
     }
-    px = st.x;
-    ph = st.h;
+    if (!was_done) { // (a finished row keeps repeating the one step after its last)
+      px = st.x;
+      ph = st.h;
+    }
     if (__all(done)) break;
   }
   if (writer) {

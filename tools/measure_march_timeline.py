@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from atm_raytracer_amd import _lib, generators, sharding, synth  # noqa: E402
+from atm_raytracer_amd import _lib, generators, synth  # noqa: E402
 
 W, H = 4096, 2048
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -20,12 +20,12 @@ g = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 cfg, tiles = synth.scene("headline", W, H, generator="Rectilinear", level=2)
 ctx = generators.Context(0)
 terrain = generators.Terrain.from_tiles(tiles, ctx)
-c0, c1 = sharding.column_shard(W, g, G)
+c0, c1 = g * W // G, (g + 1) * W // G
 cfg.params.col_begin, cfg.params.col_end = c0, c1
-slab = sharding.PlaneSlab(H, c1 - c0, torch.device("cuda", 0))
+_planes, slab_pod = generators.image_planes(H, c1 - c0, torch.device("cuda", 0))
 gen = generators.make_generator(generators.Params(cfg), terrain)
 for _ in range(4):
-    steps, ms = gen.generate_device(slab.device_planes())
+    steps, ms = gen.generate_device(slab_pod)
 n_waves = (c1 - c0) * H // 64
 buf = np.zeros(3 * 65536, dtype=np.uint64)
 lib = _lib.load()

@@ -754,12 +754,16 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (general) {
-    // Rectilinear with scene objects: the lean march, which hands the rays that can meet an object to the general tracer at the step
-    // that flags them, and the tracer beside it on the second stream, consuming that queue (launch_rect_trace_count)
-    HIP_TRY(c, c->d_object_rays.reserve(((size_t)f.wl * f.h + 64) * sizeof(uint32_t)));
+    // Rectilinear with scene objects: the lean march first (it leaves the rays that can meet an object to the general tracer and
+    // lists them), then the tracer over that list
+    HIP_TRY(c, c->d_object_rays.reserve((size_t)f.wl * f.h * sizeof(uint32_t)));
     ws.object_rays = c->d_object_rays.as<uint32_t>();
     HIP_TRY(c, hipEventRecord(ev[4], s));
-    launch_trace_count(f, ws, dense, s, c->stream2, c->ev_fork, c->ev_join);
+    launch_trace_count(f, ws, dense, s);
+    uint64_t cnt[N_COUNTERS] = {};
+    HIP_TRY(c, hipMemcpyAsync(cnt, ws.counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    launch_rect_trace_objects(f, ws, dense, cnt[11], s);
     HIP_TRY(c, hipEventRecord(ev[5], s));
     HIP_TRY(c, hipEventRecord(ev[6], s));
   } else if (fast) {
@@ -1016,8 +1020,6 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
     c->timings = t;
   }
   (void)fast;
-  if (counters[12] && f.n_objects && f.p.generator == ATMRT_GEN_RECTILINEAR)
-    return c->fail(ATMRT_ERR_HIP, "the general tracer waited 30 s for the lean march beside it to end: the two streams did not run concurrently");
   if (counters[12])
     return c->fail(ATMRT_ERR_HIP, "the time-sliced march left %llu of its ray groups unfinished", (unsigned long long)counters[12] - 1);
   c->stats.unlisted_rays = counters[4];

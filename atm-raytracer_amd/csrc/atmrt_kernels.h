@@ -85,7 +85,7 @@ struct PathSegState {
 // [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
 // together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march,
 // [11] rays of a scene with objects that the lean march left to the general tracer
-constexpr int N_COUNTERS = 16; // [11]: rays handed to the general tracer (its queue's length); [14]: queue entries claimed by tracer wavefronts; [15]: the lean march has ended; [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks); [13]: records appended to the overflow arena
+constexpr int N_COUNTERS = 14; // [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks); [13]: records appended to the overflow arena
 
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
@@ -126,18 +126,6 @@ static inline OverflowArena carve_overflow(char* base, size_t cap) {
 // small frames over the kernel the full-size frames use, and the other way round; same results every way).
 constexpr unsigned MARCH_SMALL_MAX_BLOCKS = 16384u;
 constexpr int MARCH_SLICE_STEPS = 128;
-// Workgroups (of 4 wavefronts) of the general tracer when it runs as the consumer of the lean march's queue (k_rect_trace_queue):
-// one per CU = a wavefront per SIMD — enough for the tracer's share of a frame to finish inside the march (config 5: 14 tasks per
-// wavefront at ~12 ms each against a march of ~300 ms; a tile of 1/8: 2 tasks against ~40 ms), few enough to cost the march one of
-// its four wavefronts per SIMD only while they run.  ATMRT_TRACE_QUEUE_WGS overrides (experiments).
-static inline size_t trace_queue_workgroups() {
-  static const size_t n = [] {
-    const char* env = getenv("ATMRT_TRACE_QUEUE_WGS");
-    const long v = env ? atol(env) : 0;
-    return (size_t)(v > 0 ? v : 256);
-  }();
-  return n;
-}
 static inline int march_variant_override() {
   static const int v = [] {
     const char* e = getenv("ATMRT_MARCH_VARIANT");
@@ -259,8 +247,7 @@ void launch_fast_profile_ll(const Frame& f, Workspace& ws, hipStream_t stream);
 void launch_close_count(const Frame& f, Workspace& ws, hipStream_t stream);
 void launch_close_fill(const Frame& f, Workspace& ws, hipStream_t stream);
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* tmp, uint64_t* out, unsigned long long* total, hipStream_t stream);
-void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2 = nullptr,
-                        hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
+void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
 void launch_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                        hipStream_t stream);
 void launch_fast_paths(const Frame& f, Workspace& ws, hipStream_t stream, int i_begin, int i_end); // atmrt_paths.hip
@@ -289,8 +276,8 @@ void launch_draw_image(size_t n_pixels, const atmrt_coloring_t& col, double terr
                        const uint32_t* hit_count, const uint64_t* hit_offset, const PackedHits& hits, const DensePlanes& dense,
                        uint8_t* rgb, hipStream_t stream);
 
-void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
-                             hipEvent_t ev_fork, hipEvent_t ev_join);
+void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream);
+void launch_rect_trace_objects(const Frame& f, Workspace& ws, const DensePlanes& out, uint64_t n_rays, hipStream_t stream);
 void launch_rect_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                             hipStream_t stream);
 void launch_dense_from_packed(const Frame& f, Workspace& ws, const PackedHits& packed, const DensePlanes& dense, int fast_angles,

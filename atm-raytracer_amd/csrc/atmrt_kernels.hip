@@ -1526,10 +1526,9 @@ void launch_multi_fill_fast(const Frame& f, Workspace& ws, uint64_t n_hits, cons
   launch_dense_from_packed(f, ws, packed, dense, 1, stream);
 }
 
-void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2, hipEvent_t ev_fork,
-                        hipEvent_t ev_join) {
+void launch_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
   if (f.p.generator == ATMRT_GEN_RECTILINEAR) {
-    launch_rect_trace_count(f, ws, out, stream, stream2, ev_fork, ev_join);
+    launch_rect_trace_count(f, ws, out, stream);
     return;
   }
   hipLaunchKernelGGL(k_paths_transpose, dim3(f.n_path_cap, cdiv(f.h, 256)), dim3(256), 0, stream, f, ws.pelev, ws.plen, ws.npath,

@@ -105,24 +105,6 @@ static __device__ __forceinline__ void overflow_append(const OverflowArena& ovf,
   }
 }
 
-// MODE 3: the rays of this wavefront that have just been flagged go to the general tracer NOW — k_rect_trace_queue consumes the
-// queue while this march is still running.  Everything the march stored for those pixels (slots of earlier terrain crossings,
-// which the tracer will write again) is released to agent scope first: the consumer may run on another XCD, and two dirty copies
-// of one line in two L2s are written back in no particular order.  One atomic per wavefront (wave_compact_append); the entry itself
-// — EMPTY until now — is the signal.  Called under a wave-uniform condition by every lane still marching.
-static __device__ __forceinline__ void hand_over_to_tracer(bool flagged, uint32_t p, uint32_t* __restrict__ queue,
-                                                           unsigned long long* __restrict__ counters) {
-  const unsigned long long m = __ballot(flagged);
-  if (!m) return; // wave-uniform
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-  const int leader = __builtin_ctzll(m);
-  unsigned long long base = 0;
-  if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counters[11], (unsigned long long)__builtin_popcountll(m));
-  base = __shfl(base, leader, 64);
-  if (flagged) __hip_atomic_store(queue + base + rank, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 #ifdef ATMRT_TIMELINE
 // Experiment hook (tools/measure_march_timeline.py; never defined in the product build): start / end time and steps of every
 // wavefront of the last k_rect_march launch, read back through atmrt_debug_timeline.
@@ -134,8 +116,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
-                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list, OverflowArena ovf,
-                                                    uint32_t* __restrict__ ray_queue) {
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list, OverflowArena ovf) {
 #ifdef ATMRT_TIMELINE
   const unsigned long long tl_t0 = wall_clock64();
 #endif
@@ -213,7 +194,6 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
         for (int q = 0; q < w_n && q < WAVE_CAND; q++) // first interval that is not behind the start
           if (w_hi[wv][q] >= 0.0) x_wake = w_lo[wv][q] < x_wake ? w_lo[wv][q] : x_wake;
       }
-      hand_over_to_tracer(object_ray, (uint32_t)p, ray_queue, counters); // every live lane of the wavefront is here
     }
     // first sample (PathIterator::next at the start state); the reference would panic on an empty stream
     if (!(0.0 > max_dist || alt < -1000.0) && !object_ray) {
@@ -256,7 +236,6 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
             if (!((re0 < vlo && sh < vlo) || (re0 > vhi && sh > vhi))) object_ray = true; // object_out_of_band is false
           }
           x_wake = next;
-          hand_over_to_tracer(object_ray, (uint32_t)p, ray_queue, counters); // wave-uniform block: every lane still marching is here
           if (object_ray) break;
         }
         // A sample above every post of the mosaic is above the terrain, whatever its geodesic point: ray - terrain is positive and
@@ -320,8 +299,9 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
       }
     }
     if (MODE == 3) hit_step[p] = object_ray ? 1 : 0; // voids the ray's overflow records (k_rect_scatter_trace_overflow)
-    if (MODE == 3 && object_ray) { // nothing of this ray counts: the tracer starts it again — and owns the pixel's planes from the
-      steps = 0;                   // moment it was handed over (it may have finished it already): no store here
+    if (MODE == 3 && object_ray) { // nothing of this ray counts: k_rect_trace starts it again
+      out.hit_count[p] = OBJECT_RAY;
+      steps = 0;
       lookups = 0;
     } else if (MODE != 2) {
       out.azimuth[p] = dm_to_degrees(direction); // not wrapped, rectilinear.rs:110-113
@@ -735,19 +715,27 @@ static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Eart
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
 // utils.rs:72-88), then the step logic above.
-// The rays the lean march hands to the general tracer WHILE it is still marching (scenes with objects, counting pass): a list the
-// march appends to at the step that flags a ray — entries start out EMPTY, the pixel index is written with agent scope after a
-// release of everything the march had stored for that pixel — and that tracer wavefronts consume 64 entries at a time.
-// ctl = the frame's counters: [11] entries appended, [14] entries claimed by consumers, [15] != 0: the march has ended ([11] is final).
-constexpr uint32_t QUEUE_EMPTY = 0xffffffffu;
-
-// get_single_pixel in full for pixel p (utils.rs:201-289)
+// 3 waves per SIMD (168 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above)
+#ifndef ATMRT_TRACE_WAVES
+#define ATMRT_TRACE_WAVES 3
+#endif
 template <bool FILL, int CALC, bool CUBIC>
-static __device__ __forceinline__ void trace_ray(const Frame& f, const DensePlanes& out, const uint64_t* __restrict__ hit_offset,
-                                                 const PackedHits& packed, const RectRec& rec, uint32_t* __restrict__ list_step,
-                                                 uint32_t* __restrict__ list_pixel, unsigned long long* __restrict__ counters,
-                                                 double* __restrict__ step_prop, const OverflowArena& ovf, const PackedHits& ovf_packed,
-                                                 size_t p, unsigned long long& steps) {
+__global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
+                                                    PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
+                                                    uint32_t* __restrict__ list_pixel,
+                                                    unsigned long long* __restrict__ counters,
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list,
+                                                    double* __restrict__ step_prop, OverflowArena ovf, PackedHits ovf_packed) {
+  // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
+  // (packed / rec / list_step then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its place in
+  // the pixel-ordered list, for all pixels or for the listed ones (those that did not fit their slots).
+  stage_dm_tables();
+  const size_t plane = (size_t)f.wl * f.h;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = pixel_list ? tid < n_list : tid < plane;
+  const size_t p = pixel_list ? (live ? pixel_list[tid] : 0) : tid;
+  unsigned long long steps = 0;
+  if (live) {
     const Earth e = earth_for<CALC>(f);
     const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
     const bool sph = e.spherical != 0;
@@ -923,90 +911,11 @@ static __device__ __forceinline__ void trace_ray(const Frame& f, const DensePlan
       out.hit_count[p] = count;
       if (count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
     }
-}
-
-// 3 waves per SIMD (168 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above)
-#ifndef ATMRT_TRACE_WAVES
-#define ATMRT_TRACE_WAVES 3
-#endif
-template <bool FILL, int CALC, bool CUBIC>
-__global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,
-                                                    PackedHits packed, RectRec rec, uint32_t* __restrict__ list_step,
-                                                    uint32_t* __restrict__ list_pixel,
-                                                    unsigned long long* __restrict__ counters,
-                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list,
-                                                    double* __restrict__ step_prop, OverflowArena ovf, PackedHits ovf_packed) {
-  // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
-  // (packed / rec / list_step then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its place in
-  // the pixel-ordered list, for all pixels or for the listed ones (those that did not fit their slots).
-  stage_dm_tables();
-  const size_t plane = (size_t)f.wl * f.h;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = pixel_list ? tid < n_list : tid < plane;
-  const size_t p = pixel_list ? (live ? pixel_list[tid] : 0) : tid;
-  unsigned long long steps = 0;
-  if (live) trace_ray<FILL, CALC, CUBIC>(f, out, hit_offset, packed, rec, list_step, list_pixel, counters, step_prop, ovf, ovf_packed, p, steps);
+  }
   if (!FILL) {
     steps = wave_sum(steps);
     if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
   }
-}
-
-// The counting pass of the tracer as a CONSUMER of the lean march's queue: a bounded grid (a wavefront per SIMD at most) that runs
-// beside k_rect_march<3> on a second stream.  The tracer alone is a launch of under two wavefronts per SIMD — config 5: 38 ms for
-// the frame, 12 ms for a tile of ANY size, at the speed of a lone wavefront's dependency chain — and the rays it needs are known
-// within the first few per cent of the march; beside the march its chain hides behind the march's arithmetic.  Each wavefront
-// claims 64 entries, waits (sleeping) until the march has written them or has ended short of them, traces them, and claims again.
-// Priority 3: the tracer's wavefronts are few and their chain is the critical path once the march has drained.
-template <int CALC, bool CUBIC>
-__global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace_queue(Frame f, DensePlanes out, PackedHits packed, RectRec rec,
-                                                                           uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
-                                                                           unsigned long long* __restrict__ counters,
-                                                                           const uint32_t* __restrict__ queue, OverflowArena ovf,
-                                                                           PackedHits ovf_packed) {
-  stage_dm_tables();
-  __builtin_amdgcn_s_setprio(3);
-  const int lane = threadIdx.x & 63;
-  unsigned long long steps = 0;
-  for (;;) {
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&counters[14], 64ull);
-    base = __shfl(base, 0, 64);
-    const unsigned long long mine = base + (unsigned long long)lane;
-    uint32_t p = QUEUE_EMPTY;
-    bool beyond = false; // the march has ended and never wrote this entry
-    const unsigned long long wait_t0 = wall_clock64();
-    for (int backoff = 1;; backoff = backoff < 8 ? backoff * 2 : 8) {
-      if (p == QUEUE_EMPTY && !beyond) {
-        // the order matters: first whether the march has ended, then the entry — an entry still empty after the end was seen
-        // will never be written (the end flag is set by a kernel that follows the march on its stream)
-        const unsigned long long ended = __hip_atomic_load(&counters[15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        p = __hip_atomic_load(queue + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p == QUEUE_EMPTY && ended) beyond = true;
-      }
-      if (__all(p != QUEUE_EMPTY || beyond)) break;
-      if (wall_clock64() - wait_t0 > 3000000000ull) { // 30 s at 100 MHz without the march ending: it is not running beside us (the
-        if (lane == 0) atomicMax(&counters[12], 3ull); // two streams were serialised?) — fail the frame instead of hanging the GPU
-        beyond = true;
-        if (p != QUEUE_EMPTY) p = QUEUE_EMPTY;
-        break;
-      }
-      __builtin_amdgcn_s_setprio(0);
-      for (int k = 0; k < backoff; k++) __builtin_amdgcn_s_sleep(127); // 127 x 64 cycles = 3.4 us
-      __builtin_amdgcn_s_setprio(3);
-    }
-    if (!__any(p != QUEUE_EMPTY)) break; // nothing left for this wavefront: every later claim is beyond the end too
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // what the march had stored for these pixels before it handed them over
-    if (p != QUEUE_EMPTY)
-      trace_ray<false, CALC, CUBIC>(f, out, nullptr, packed, rec, list_step, list_pixel, counters, nullptr, ovf, ovf_packed, (size_t)p, steps);
-  }
-  steps = wave_sum(steps);
-  if (lane == 0 && steps) atomicAdd(&counters[0], steps);
-}
-
-// the march has ended: counters[11] is the final length of the queue
-static __global__ void k_queue_end(unsigned long long* __restrict__ counters) {
-  __hip_atomic_store(&counters[15], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1064,7 +973,7 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
   if (f.opaque) {
     if (!launch_rect_march_sliced<0, CUBIC>(f, ws, out, SliceSinks{ws.hit_step, rec, nullptr, OverflowArena{}}, stream)) {
       ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{}, (uint32_t*)nullptr);
+                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{});
     }
     (void)hipEventRecord(ev_marched, stream);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
@@ -1074,7 +983,7 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
     const OverflowArena ovf = carve_overflow(ws.overflow_arena, ws.overflow_cap);
     if (!launch_rect_march_sliced<1, CUBIC>(f, ws, out, SliceSinks{nullptr, slots, ws.slot_step, ovf}, stream)) {
       ATMRT_LAUNCH_MARCH(1, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, (uint32_t*)nullptr,
-                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, ovf, (uint32_t*)nullptr);
+                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, ovf);
     }
     (void)hipEventRecord(ev_marched, stream);
   }
@@ -1147,7 +1056,7 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
                          ws.list_pixel, rec);
   } else if (ws.n_overflow) {
     ATMRT_LAUNCH_MARCH(2, ws.n_overflow, stream, f, dense, ws.hit_step, ws.hit_offset, rec, ws.list_step, ws.list_pixel,
-                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow, OverflowArena{}, (uint32_t*)nullptr);
+                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow, OverflowArena{});
   }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
@@ -1157,33 +1066,41 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
 }
 
 
+// the rays k_rect_march<3> left to the tracer, collected into a list (order irrelevant: every ray is independent); counters[11] = their number
+static __global__ __launch_bounds__(256) void k_collect_object_rays(size_t n, const uint32_t* __restrict__ hit_count,
+                                                                    uint32_t* __restrict__ list, unsigned long long* __restrict__ counters) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  wave_compact_append(p < n && hit_count[p] == OBJECT_RAY, (uint32_t)p, list, &counters[11]); // the rays the general tracer visits
+}
+
 // the overflow arena of a scene with objects: records + complete points
 static inline OverflowArena trace_overflow_arena(const Workspace& ws) {
   OverflowArena a = carve_overflow(ws.overflow_arena, ws.overflow_cap);
   if (a.cap) a.color_tag = ws.overflow_packed.color_tag;
   return a;
 }
-// Scenes with objects, counting pass (launch_rect_trace_count, atmrt_march_linear.hip): the lean march over every pixel on one
-// stream (terrain crossings into the tracer's slot arena; a ray that can meet an object is handed to the tracer at the step that
-// flags it) and, beside it on a second stream, the general tracer as the consumer of that queue (k_rect_trace_queue: a wavefront
-// per SIMD at most).  The tracer is launched FIRST — its few workgroups take their places, the march fills the rest of the chip
-// around them — and the march's stream rejoins it at the end.
+// Scenes with objects, counting pass, phase 1: the lean march over every pixel (terrain crossings into the tracer's slot arena,
+// rays that can meet an object flagged and listed); phase 2 (launch_rect_trace_objects_t, after the host has read the list's
+// length) traces the listed rays with the general tracer.
 template <bool CUBIC>
-void launch_rect_march3_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
   ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
-                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws), ws.object_rays);
-  hipLaunchKernelGGL(k_queue_end, dim3(1), dim3(1), 0, stream, (unsigned long long*)ws.counters);
+                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws));
+  hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
+                     (unsigned long long*)ws.counters);
 }
 template <bool CUBIC>
-void launch_rect_trace_queue_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+void launch_rect_trace_objects_t(const Frame& f, Workspace& ws, const DensePlanes& out, uint64_t n_rays, hipStream_t stream) {
+  if (!n_rays) return;
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
-  const unsigned consumers = (unsigned)std::min<size_t>(trace_queue_workgroups(), cdiv(n, 256));
-  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace_queue<CALC, CUBIC>), dim3(consumers), dim3(256), 0, stream, f, out,
-                                                        ws.slot_packed, slots, ws.slot_step, ws.slot_pixel, (unsigned long long*)ws.counters,
-                                                        (const uint32_t*)ws.object_rays, trace_overflow_arena(ws), ws.overflow_packed));
+  ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_trace<false, CALC, CUBIC>), dim3(cdiv((size_t)n_rays, 256)), dim3(256), 0, stream, f, out,
+                                                        (const uint64_t*)nullptr, ws.slot_packed, slots, ws.slot_step,
+                                                        ws.slot_pixel, (unsigned long long*)ws.counters,
+                                                        (const uint32_t*)ws.object_rays, (uint32_t)n_rays, (double*)nullptr,
+                                                        trace_overflow_arena(ws), ws.overflow_packed));
 }
 
 // Trace points kept in the slot arena by the counting pass of k_rect_trace, moved to their places in the pixel-ordered list
@@ -1302,9 +1219,9 @@ void launch_rect_trace_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, co
   template void launch_rect_march_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t, hipEvent_t);            \
   template void launch_multi_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,         \
                                            hipStream_t);                                                                      \
-  template void launch_rect_march3_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
+  template void launch_rect_trace_count_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
 #define ATMRT_INSTANTIATE_TRACE(CUBIC)                                                                                        \
-  template void launch_rect_trace_queue_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);                  \
+  template void launch_rect_trace_objects_t<CUBIC>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t);      \
   template void launch_rect_trace_fill_t<CUBIC>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&,    \
                                                 hipStream_t);
 

@@ -7,10 +7,10 @@ ATMRT_INSTANTIATE_MARCH(false)
 // the non-template entry points pick the variant by whether the compiled atmosphere has Spline (cubic) segments
 extern template void launch_rect_march_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t, hipEvent_t);
 extern template void launch_multi_fill_t<true>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
-extern template void launch_rect_march3_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
-extern template void launch_rect_trace_queue_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
+extern template void launch_rect_trace_count_t<true>(const Frame&, Workspace&, const DensePlanes&, hipStream_t);
+extern template void launch_rect_trace_objects_t<true>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t);
 extern template void launch_rect_trace_fill_t<true>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
-extern template void launch_rect_trace_queue_t<false>(const Frame&, Workspace&, const DensePlanes&, hipStream_t); // atmrt_trace_linear.hip
+extern template void launch_rect_trace_objects_t<false>(const Frame&, Workspace&, const DensePlanes&, uint64_t, hipStream_t); // atmrt_trace_linear.hip
 extern template void launch_rect_trace_fill_t<false>(const Frame&, Workspace&, uint64_t, const DensePlanes&, const PackedHits&, hipStream_t);
 
 void launch_rect_march(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipEvent_t ev_marched) {
@@ -22,22 +22,13 @@ void launch_multi_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const Den
   if (f.atm_cubic) launch_multi_fill_t<true>(f, ws, n_hits, dense, packed, stream);
   else launch_multi_fill_t<false>(f, ws, n_hits, dense, packed, stream);
 }
-void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream, hipStream_t stream2,
-                             hipEvent_t ev_fork, hipEvent_t ev_join) {
-  const size_t n = (size_t)f.wl * f.h;
-  (void)hipMemsetAsync(ws.object_rays, 0xff, n * sizeof(uint32_t), stream); // QUEUE_EMPTY; counters [11], [14], [15] are zero (frame start)
-  (void)hipEventRecord(ev_fork, stream);
-  (void)hipStreamWaitEvent(stream2, ev_fork, 0);
-  // The march first, its consumer second.  Two streams of a process may share a hardware queue, which runs its kernels in order: a
-  // consumer ahead of the march it waits for would wait forever.  In this order no consumer precedes its own march in any queue,
-  // and a cycle through another context's kernels would need one of them to have been submitted before itself.  (The consumer
-  // still gives up after 30 s without its march ending — counters[12] — rather than hang the GPU.)
-  if (f.atm_cubic) launch_rect_march3_t<true>(f, ws, out, stream);
-  else launch_rect_march3_t<false>(f, ws, out, stream);
-  if (f.atm_cubic) launch_rect_trace_queue_t<true>(f, ws, out, stream2);
-  else launch_rect_trace_queue_t<false>(f, ws, out, stream2);
-  (void)hipEventRecord(ev_join, stream2);
-  (void)hipStreamWaitEvent(stream, ev_join, 0);
+void launch_rect_trace_count(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
+  if (f.atm_cubic) launch_rect_trace_count_t<true>(f, ws, out, stream);
+  else launch_rect_trace_count_t<false>(f, ws, out, stream);
+}
+void launch_rect_trace_objects(const Frame& f, Workspace& ws, const DensePlanes& out, uint64_t n_rays, hipStream_t stream) {
+  if (f.atm_cubic) launch_rect_trace_objects_t<true>(f, ws, out, n_rays, stream);
+  else launch_rect_trace_objects_t<false>(f, ws, out, n_rays, stream);
 }
 void launch_rect_trace_fill(const Frame& f, Workspace& ws, uint64_t n_hits, const DensePlanes& dense, const PackedHits& packed,
                             hipStream_t stream) {

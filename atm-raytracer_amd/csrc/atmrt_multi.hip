@@ -1260,6 +1260,7 @@ int atmrt::multi_generate(atmrt_ctx* parent, atmrt_result_t* out) {
       run += g->kids[i]->comm->row_total[(size_t)y];
     }
   // (4) every device's host thread moves its own segments and writes its pixels' offsets
+  const auto merge_t0 = std::chrono::steady_clock::now();
   rc = multi_forward(parent, [&](atmrt_ctx* k) {
     Comm* cm = k->comm;
     const size_t i = (size_t)cm->rank;
@@ -1296,6 +1297,7 @@ int atmrt::multi_generate(atmrt_ctx* parent, atmrt_result_t* out) {
   tm.world = (int32_t)n;
   tm.route = ATMRT_ROUTE_HOST;
   tm.tile_ms_min = 1e300;
+  tm.assemble_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - merge_t0).count(); // the host merge of the lists
   for (size_t i = 0; i < n; i++) {
     atmrt_ctx* k = g->kids[i];
     float v = 0.f;

@@ -400,7 +400,7 @@ typedef enum atmrt_gather_route {
 } atmrt_gather_route;
 typedef struct atmrt_comm_timings {
   double gather_ms;         /* the collective (or the copies) */
-  double assemble_ms;       /* permutation of the gathered tiles into the [H][W] planes */
+  double assemble_ms;       /* permutation of the gathered tiles into the [H][W] planes (route HOST: the merge of the lists on the host threads, wall clock) */
   double tile_ms_max;       /* slowest device's generate time */
   double tile_ms_min;       /* fastest device's */
   uint64_t bytes_per_rank;  /* what each rank contributed to the collective */

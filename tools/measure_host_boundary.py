@@ -34,8 +34,8 @@ def measure(ctx, cfg, tiles, out, suffix=""):
         wall = sum(times) / len(times)
         out[name + suffix] = {"wall_ms": wall * 1e3, "device_ms": dev_ms, "result_bytes": int(nbytes), "ray_steps": int(steps),
                      "ray_steps_per_s_pcie_inclusive": steps / wall, "ray_steps_per_s_device": steps / (dev_ms * 1e-3)}
-    if suffix:
-        out["comm" + suffix] = ctx.comm_timings()
+        if suffix and not suffix.endswith("_config5"):
+            out[name + suffix]["comm"] = ctx.comm_timings()
     ctx.close()
 
 
@@ -43,10 +43,17 @@ def main():
     out = {}
     cfg, tiles = synth.scene("headline", level=2)
     measure(generators.Context(0), cfg, tiles, out)
-    # the multi-device route of atmrt_generate (csrc/atmrt_multi.hip) with two sub-contexts on the ONE GPU of this box: the two
-    # tiles share the device, so the device time is that of the whole frame; what the line shows is the cost of the host-side
-    # assembly (strided plane copies + the merge of the trace-point lists on two host threads) on top of it
+    # the multi-device route of atmrt_generate (csrc/atmrt_multi.hip) with two / eight sub-contexts on the ONE GPU of this box: the
+    # tiles share the device, so the device time is that of the whole frame; what the lines show is the cost of the host-side
+    # assembly (strided plane copies + the merge of the trace-point lists on the devices' host threads) on top of it —
+    # comm.gather_ms: the device-to-host copies (slowest device), comm.assemble_ms: the merge (wall clock)
     measure(generators.Context.multi([0, 0]), cfg, tiles, out, suffix="_two_tiles_one_gpu")
+    measure(generators.Context.multi([0] * 8), cfg, tiles, out, suffix="_eight_tiles_one_gpu")
+    # BASELINE config 5: the headline with translucent terrain and 1000 objects (several trace points per pixel: the lists are 4x longer)
+    cfg5, _ = synth.scene("headline", level=2, terrain_alpha=0.5)
+    synth.add_objects(cfg5)
+    measure(generators.Context(0), cfg5, tiles, out, suffix="_config5")
+    measure(generators.Context.multi([0] * 8), cfg5, tiles, out, suffix="_config5_eight_tiles_one_gpu")
     print(json.dumps(out))
 
 

@@ -1459,7 +1459,7 @@ extern "C" int atmrt_coords_at_dist(atmrt_ctx* c, double lat0, double lon0, doub
 }
 
 extern "C" int atmrt_math_probe(atmrt_ctx* c, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1) {
-  if (!c || (n && (!a || !out0)) || op < 0 || op > ATMRT_PROBE_DIV_SEED_N) return ATMRT_ERR_INVALID_ARGUMENT;
+  if (!c || (n && (!a || !out0)) || op < 0 || op > ATMRT_PROBE_POW3_SHARED) return ATMRT_ERR_INVALID_ARGUMENT;
   FORWARD_TO_FIRST_DEVICE(c, atmrt_math_probe(k_, op, n, a, b, out0, out1));
   if (!n) return ATMRT_OK;
   HIP_TRY(c, hipSetDevice(c->device));

@@ -48,7 +48,7 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // dh = h - hb.  Linear segments (cubic == 0) use the closed-form hydrostatic pressure, cubic ones a 5-point
 // Gauss-Legendre quadrature of dh/T.
 // Any number of segments (the reference's AtmosphereDef holds `Vec`s: README.md:283-323, params.rs:453-454): the table is a
-// 32-byte header followed, in the same allocation, by its n segments — one 96-byte record each, so the parameters of the
+// 32-byte header followed, in the same allocation, by its n segments — one 104-byte record each, so the parameters of the
 // wave-uniform hinted layer are one run of scalar loads and a per-lane layer is one gather base.
 struct AtmSeg {
   double hb;    // reference altitude of the segment
@@ -71,6 +71,10 @@ struct AtmSeg {
   // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-10.5 — so dm_div3 needs no
   // vote on its seeds, 2 - Z seeds the reciprocal of Z and 1 - (n - 1) that of n (dm_div3_seeded, dm_div_seeded).
   int32_t flags;
+  // TIGHT segments: 1/2 - margin, where margin bounds |e_i - e_0| 128 / ln2 for the arguments e of exp at the three evaluation
+  // points of one right-hand side — dm_exp3_main_shared shares its table row among them while the centre's product is at most
+  // this far from an integer (negative: never)
+  double exp_thr;
 };
 constexpr int32_t ATM_SEG_ISOTHERMAL = 1, ATM_SEG_TIGHT = 2;
 struct AtmTable {
@@ -81,7 +85,7 @@ struct AtmTable {
   ATMRT_HD const AtmSeg& seg(int k) const { return reinterpret_cast<const AtmSeg*>(this + 1)[k]; }
   ATMRT_HD AtmSeg& seg(int k) { return reinterpret_cast<AtmSeg*>(this + 1)[k]; }
 };
-static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 96, "device and host read the table as header + records");
+static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 104, "device and host read the table as header + records");
 // the table in the constant address space (it is read-only for a whole launch): wave-uniform indices become scalar loads
 #if defined(__HIPCC__)
 typedef const __attribute__((address_space(4))) AtmTable* AtmConstTable;
@@ -449,6 +453,13 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
     t.seg(k).safe_lo = dm_inf();
     t.seg(k).safe_hi = -dm_inf();
     t.seg(k).flags = !t.seg(k).cubic && t.seg(k).lapse == 0.0 ? ATM_SEG_ISOTHERMAL : 0;
+    // the exponents of the three points of one right-hand side: e = expo log(T / tb), log arguments within 2^-21 of one another on
+    // a tight segment (+ the rounding of log itself: 4 ulp of a value below 12), or e = expo (h - hb) with h 1 cm apart
+    const double ae = dm_fabs(t.seg(k).expo);
+    const double de = t.seg(k).lapse != 0.0 ? ae * (4.76837158203125e-07 + 1.0e-14) : ae * 0.01 * (1.0 + 1.0e-9);
+    const double margin = 1.01 * de * DM_INVLN2N + 1.0e-6;
+    t.seg(k).exp_thr = margin < 0.5 ? 0.5 - margin : -1.0; // (NaN: -1)
+    if (!(t.seg(k).exp_thr >= 0.0)) t.seg(k).exp_thr = -1.0;
   }
   t.alt_lo = dm_inf();
   t.alt_hi = -dm_inf();
@@ -645,12 +656,42 @@ ATMRT_HD void pow3_in_range(double x0, double x1, double x2, double y, double& r
   r1 = dm_exp_main(e1);
   r2 = dm_exp_main(e2);
 }
+// the same on a TIGHT segment: the shared-row forms of detmath.h where no lane sits on a table edge (wave votes), else the plain ones
+ATMRT_HD void pow3_tight(double x0, double x1, double x2, double y, double thr, double& r0, double& r1, double& r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double l0, l1, l2;
+  if (!dm_log3_core_pow_shared(x0, x1, x2, &l0, &l1, &l2)) {
+    l0 = dm_log_core_pow(x0);
+    l1 = dm_log_core_pow(x1);
+    l2 = dm_log_core_pow(x2);
+  }
+  const double e0 = y * l0, e1 = y * l1, e2 = y * l2;
+  if (!dm_exp3_main_shared(e0, e1, e2, thr, &r0, &r1, &r2)) {
+    r0 = dm_exp_main(e0);
+    r1 = dm_exp_main(e1);
+    r2 = dm_exp_main(e2);
+  }
+#else
+  (void)thr;
+  pow3_in_range(x0, x1, x2, y, r0, r1, r2);
+#endif
+}
+ATMRT_HD void exp3_tight(double e0, double e1, double e2, double thr, double& r0, double& r1, double& r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (dm_exp3_main_shared(e0, e1, e2, thr, &r0, &r1, &r2)) return;
+#else
+  (void)thr;
+#endif
+  r0 = dm_exp_main(e0);
+  r1 = dm_exp_main(e1);
+  r2 = dm_exp_main(e2);
+}
 // Only for points inside a certified interval [safe_lo, safe_hi) of a segment (the callers' wave votes): there T / tb is a positive
 // normal number and |expo log(T / tb)| (|expo (h - hb)| on an isothermal segment) is at most 645, so log and exp take their main
 // branches unasked — the values of refr_n_layer at the three points.
 template <bool CUBIC = true>
-ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double hb, double tb, double rtb, double pb, double lapse, double c2, double c3,
-                            double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2, double& q0) {
+ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr, double hb, double tb, double rtb, double pb, double lapse,
+                            double c2, double c3, double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2, double& q0) {
   if (CUBIC && cubic) {
     n0 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
     n1 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
@@ -659,6 +700,12 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double hb, doub
   }
   const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
   double r0, r1, r2;
+  if (flags & ATM_SEG_TIGHT) {
+    if (!(flags & ATM_SEG_ISOTHERMAL)) pow3_tight(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, exp_thr, r0, r1, r2);
+    else exp3_tight(expo * (h0 - hb), expo * (h1 - hb), expo * (h2 - hb), exp_thr, r0, r1, r2);
+    refr_from_tp3_tight(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2, q0);
+    return;
+  }
   if (!(flags & ATM_SEG_ISOTHERMAL)) {
     pow3_in_range(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
   } else {
@@ -666,8 +713,7 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double hb, doub
     r1 = dm_exp_main(expo * (h1 - hb));
     r2 = dm_exp_main(expo * (h2 - hb));
   }
-  if (flags & ATM_SEG_TIGHT) refr_from_tp3_tight(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2, q0);
-  else refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
+  refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
 }
 
 // Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).  IEEE operations throughout: the
@@ -753,8 +799,9 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
     const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = ks->flags;
+    const double exp_thr = ks->exp_thr;
     double n1, n2, q0;
-    refr_n_layer3<CUBIC>(k_refr, cubic, flags, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
     dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
     return true;
   }
@@ -1163,8 +1210,9 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi && !(dm_fabs(b) > ACCEL_FAST_MAX_B))) {
     const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = ks->flags;
+    const double exp_thr = ks->exp_thr;
     double n, n1, n2, q0;
-    refr_n_layer3<CUBIC>(k_refr, cubic, flags, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
     const double dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
     fast = true;
     if ((flags & ATM_SEG_TIGHT) && !(CUBIC && cubic)) return accel_rhs_tight(spherical, a, b, n, q0, dn);

@@ -1377,6 +1377,13 @@ __global__ void k_math_probe(int op, size_t n, const double* __restrict__ a, con
       break;
     }
     case ATMRT_PROBE_DIV_SEED_N: r0 = dm_div_seeded(x, 1.0 + y, 1.0 - y); break;
+    case ATMRT_PROBE_POW3_SHARED: { // as refr_n_layer3 calls it on a tight segment (the threshold as atm_certify computes it)
+      const double margin = 1.01 * (dm_fabs(y) * (4.76837158203125e-07 + 1.0e-14)) * DM_INVLN2N + 1.0e-6;
+      double p1, p2;
+      pow3_tight(x, x * 0.99999976158142090, x * 1.00000023841857910, y, margin < 0.5 ? 0.5 - margin : -1.0, r0, p1, p2);
+      r1 = p1 + p2;
+      break;
+    }
     default: break;
   }
   out0[i] = r0;

@@ -68,7 +68,7 @@ DM_FN double dm_to_degrees(double rad) { return rad * DM_DEG_PER_RAD; }
  *   DM_FMA_VVS(a, b, K)      a * b + K      K: scalar constant
  *   DM_FMA_VSV(a, K, v)      a * K + v      K: scalar constant, v: a value that lives in a VGPR (possibly itself a constant)
  *   DM_FNMA_VVV(a, b, c)     c - a * b      the residual of a Newton step: the negation is a source modifier, not a v_xor + v_mov */
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DM_PLAIN_FMA)
 static __device__ __forceinline__ double dm_fma_vvs_(double a, double b, double k) {
   double d;
   __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
@@ -592,6 +592,72 @@ DM_FN double dm_log_core_pow(double x) {
   p = DM_FMA(r, p, -0.5);
   return w + (DM_FMA(r2, p, r) + lo);
 }
+/* Three-point forms for the stepping kernels: n(h), n(h - eps), n(h + eps) of one ODE right-hand side evaluate log and exp at
+ * arguments that a certificate (atm_certify, TIGHT segments) places within 2^-21 of one another.  Then the three calls of
+ * dm_log_core_pow almost always read the SAME table row with the SAME exponent, and the three calls of dm_exp_main the same 2^(j/128)
+ * entry: each form computes that shared part once — u, k, the row address, two table reads, kd, k ln2 + log c (log: 8 VALU
+ * instructions and 2 LDS reads per extra point; exp: 6 and 1) — and returns, wave-uniformly, whether it could:
+ *   log: the high words of the arguments differ by at most one unit (2^-21 relative is half a unit), so the centres agree unless
+ *        (hi_0 + 0x1000) & 0x1fff is 0 or 0x1fff — the centre argument sits on the edge of its table interval;
+ *   exp: |e_i - e_0| 128 / ln2 <= margin (the segment's bound, `thr` = 1/2 - margin), so rint(e_i 128 / ln2) = rint(e_0 128 / ln2)
+ *        unless the centre's own product lies within margin of a half-integer.
+ * One lane at an edge sends its wavefront through the plain calls (the caller's other branch); the values are those of the plain
+ * calls bit for bit either way — same operations on the same operands.  GPU only; tests/test_gpu_detmath.py (POW3_SHARED). */
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_FN int dm_log3_core_pow_shared(double x0, double x1, double x2, double* l0, double* l1, double* l2) {
+  const uint64_t i0 = dm_bits(x0), i1 = dm_bits(x1), i2 = dm_bits(x2);
+  const uint32_t h0 = (uint32_t)(i0 >> 32), h1 = (uint32_t)(i1 >> 32), h2 = (uint32_t)(i2 >> 32);
+  const uint32_t low = (h0 + 0x1000u) & 0x1fffu;
+  if (!__all(low - 1u < 0x1ffeu)) return 0; /* 1 .. 0x1ffe */
+  const int32_t u = DM_LOG_CENTRE(h0);
+  const int32_t k = u >> 20;
+  const double* t = DM_LOG_ROW_OF(u);
+  const uint32_t base = (uint32_t)u & 0xfff00000u;
+  const double z0 = dm_from_bits((i0 & 0xffffffffULL) | ((uint64_t)(h0 - base) << 32));
+  const double z1 = dm_from_bits((i1 & 0xffffffffULL) | ((uint64_t)(h1 - base) << 32));
+  const double z2 = dm_from_bits((i2 & 0xffffffffULL) | ((uint64_t)(h2 - base) << 32));
+  const double invc = t[0];
+  const double kd = (double)k;
+  const double w = DM_FMA(kd, DM_LN2_HI, t[1]);
+  const double lo = DM_FMA(kd, DM_LN2_LO, t[2]);
+  const double r0 = DM_FMA(z0, invc, -1.0), r1 = DM_FMA(z1, invc, -1.0), r2 = DM_FMA(z2, invc, -1.0);
+  double p0, p1, p2;
+  p0 = DM_FMA_VSV(r0, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  p1 = DM_FMA_VSV(r1, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  p2 = DM_FMA_VSV(r2, 1.42857142857142857e-01, -1.66666666666666667e-01);
+  p0 = DM_FMA_VVS(r0, p0, 0.2), p1 = DM_FMA_VVS(r1, p1, 0.2), p2 = DM_FMA_VVS(r2, p2, 0.2);
+  p0 = DM_FMA_VVS(r0, p0, -0.25), p1 = DM_FMA_VVS(r1, p1, -0.25), p2 = DM_FMA_VVS(r2, p2, -0.25);
+  p0 = DM_FMA_VVS(r0, p0, 3.33333333333333333e-01), p1 = DM_FMA_VVS(r1, p1, 3.33333333333333333e-01), p2 = DM_FMA_VVS(r2, p2, 3.33333333333333333e-01);
+  p0 = DM_FMA(r0, p0, -0.5), p1 = DM_FMA(r1, p1, -0.5), p2 = DM_FMA(r2, p2, -0.5);
+  *l0 = w + (DM_FMA(r0 * r0, p0, r0) + lo);
+  *l1 = w + (DM_FMA(r1 * r1, p1, r1) + lo);
+  *l2 = w + (DM_FMA(r2 * r2, p2, r2) + lo);
+  return 1;
+}
+DM_FN int dm_exp3_main_shared(double e0, double e1, double e2, double thr, double* y0, double* y1, double* y2) {
+  const double t0 = e0 * DM_INVLN2N;
+  const double kd = dm_rint(t0);
+  if (!__all(dm_fabs(t0 - kd) <= thr)) return 0; /* false for NaN */
+  const int32_t ki = (int32_t)kd;
+  const double* t = DM_EXP_ROW(ki & 127);
+  const int32_t e = ki >> 7;
+  const double th = t[0], tl = t[1];
+  double r0 = DM_FMA(-kd, DM_LN2N_HI, e0), r1 = DM_FMA(-kd, DM_LN2N_HI, e1), r2 = DM_FMA(-kd, DM_LN2N_HI, e2);
+  r0 = DM_FMA(-kd, DM_LN2N_LO, r0), r1 = DM_FMA(-kd, DM_LN2N_LO, r1), r2 = DM_FMA(-kd, DM_LN2N_LO, r2);
+  double q0, q1, q2;
+  q0 = DM_FMA_VSV(r0, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  q1 = DM_FMA_VSV(r1, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  q2 = DM_FMA_VSV(r2, 8.33333333333333333e-03, 4.16666666666666667e-02);
+  q0 = DM_FMA_VVS(r0, q0, 1.66666666666666667e-01), q1 = DM_FMA_VVS(r1, q1, 1.66666666666666667e-01), q2 = DM_FMA_VVS(r2, q2, 1.66666666666666667e-01);
+  q0 = DM_FMA(r0, q0, 0.5), q1 = DM_FMA(r1, q1, 0.5), q2 = DM_FMA(r2, q2, 0.5);
+  const double p0 = DM_FMA(r0 * r0, q0, r0), p1 = DM_FMA(r1 * r1, q1, r1), p2 = DM_FMA(r2 * r2, q2, r2);
+  *y0 = DM_SCALBN(th + DM_FMA(th, p0, tl), e);
+  *y1 = DM_SCALBN(th + DM_FMA(th, p1, tl), e);
+  *y2 = DM_SCALBN(th + DM_FMA(th, p2, tl), e);
+  return 1;
+}
+#endif
+
 DM_FN double dm_log_slow(double x) { /* nan, negative, zero, inf, subnormal */
   if (dm_isnan(x)) return x + x;
   if (x < 0.0) return (x - x) / (x - x);

@@ -480,7 +480,9 @@ typedef enum atmrt_math_probe_op {
                                    for divisors b (1 -+ 2^-22), no vote */
   ATMRT_PROBE_DIV3_SEED_Z = 16, /* dm_div3_seeded with b = Z close to 1 (|1 - Z| <= 2^-10.5) and 2 - Z as the seed of its reciprocal:
                                    out0 = a / b, out1 = a / (b (1 + 2^-22)) */
-  ATMRT_PROBE_DIV_SEED_N = 17   /* dm_div_seeded(a, 1 + b, 1 - b) for 0 <= b <= 2^-10.5: a / n with n = 1 + (n - 1) */
+  ATMRT_PROBE_DIV_SEED_N = 17,  /* dm_div_seeded(a, 1 + b, 1 - b) for 0 <= b <= 2^-10.5: a / n with n = 1 + (n - 1) */
+  ATMRT_PROBE_POW3_SHARED = 18  /* the three-point pow of a TIGHT segment (shared table rows, csrc/detmath.h): out0 = dm_pow(a, b),
+                                   out1 = dm_pow(a (1 - 2^-22), b) + dm_pow(a (1 + 2^-22), b) */
 } atmrt_math_probe_op;
 int atmrt_math_probe(atmrt_ctx* ctx, int32_t op, size_t n, const double* a, const double* b, double* out0, double* out1);
 

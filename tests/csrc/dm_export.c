@@ -38,3 +38,9 @@ void t_div3_seed_z(const double* a, const double* b, double* y0, double* y1, siz
 void t_div_seed_n(const double* a, const double* b, double* y, size_t n) {
   for (size_t i = 0; i < n; i++) y[i] = dm_div_seeded(a[i], 1.0 + b[i], 1.0 - b[i]);
 }
+void t_pow3_shared(const double* a, const double* b, double* y0, double* y1, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    y0[i] = dm_pow(a[i], b[i]);
+    y1[i] = dm_pow(a[i] * 0.99999976158142090, b[i]) + dm_pow(a[i] * 1.00000023841857910, b[i]);
+  }
+}

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 N = 10_000_000
 OPS = dict(DIV=0, DIV_R=1, SQRT_INRANGE=2, EXP=3, LOG=4, POW=5, SINCOS=6, ASIN=7, ATAN2=8, IEEE_DIV=9, IEEE_SQRT=10, ATAN=11,
-           TAN=12, POW3=13, DIV3=14, DIV3_SEEDED=15, DIV3_SEED_Z=16, DIV_SEED_N=17)
+           TAN=12, POW3=13, DIV3=14, DIV3_SEEDED=15, DIV3_SEED_Z=16, DIV_SEED_N=17, POW3_SHARED=18)
 
 
 @pytest.fixture(scope="module")
@@ -178,6 +178,35 @@ def test_seeded_divisions_of_tight_segments_give_ieee_quotients(gpu_ctx, host):
     got = gpu(gpu_ctx, "DIV_SEED_N", x, q)
     same(got, x / (1.0 + q), "X / n seeded by 1 - (n - 1)")
     same(got, cpu(host, "div_seed_n", x, q), "dm_div_seeded vs host")
+
+
+def test_shared_row_pow_of_tight_segments_is_the_plain_pow(gpu_ctx, host):
+    """Round 4: on a TIGHT segment the three pow evaluations of one right-hand side share one log table row and one exp table entry
+    where the centre argument is not at a table edge (csrc/detmath.h dm_log3_core_pow_shared / dm_exp3_main_shared; wave votes, else
+    the plain calls).  The values must be dm_pow's bit for bit: the barometric population, bases AT the edges of the log table's
+    intervals (centre +- one unit of the high word, where a neighbour's row differs) and exponent products at the half-integers of
+    exp's reduction — in wavefronts of their own and mixed into ordinary wavefronts."""
+    rng = np.random.default_rng(43)
+    x = rng.uniform(0.72, 1.39, N)
+    y = rng.choice([5.2558761132785179, -17.08, 34.163, -3.4e-4 * 288.0, 1.0, -11.388], N)
+    # bases on the edges of the 128 table intervals: high word with (hi + 0x1000) & 0x1fff in {0x1fff, 0, 1}, any low word
+    edge = rng.integers(0, N, N // 6)
+    hi = (0x3fe6a000 + rng.integers(0, 128, edge.size) * 0x2000 + rng.choice([-0x1001, -0x1000, -0xfff, 0xfff, 0x1000], edge.size)).astype(np.uint64)
+    lo = rng.integers(0, 2 ** 32, edge.size).astype(np.uint64)
+    lo[::3] = rng.choice(np.array([0, 1, 2 ** 32 - 1], dtype=np.uint64), lo[::3].size)
+    x[edge] = ((hi << np.uint64(32)) | lo).view(np.float64)
+    x[: N // 8] = np.sort(x[: N // 8])  # wavefronts of neighbours: whole wavefronts on one row, some of them all on an edge
+    # exponent products at the half-integers of exp's reduction: y log x = (k + 1/2) ln2 / 128 up to rounding
+    half = rng.integers(N // 2, N, N // 6)
+    kk = rng.integers(-60, 60, half.size)
+    with np.errstate(all="ignore"):
+        x[half] = np.exp((kk + 0.5) * np.log(2.0) / 128.0 / y[half]) * (1.0 + rng.choice([0.0, 1e-9, -1e-9, 4e-7, -4e-7], half.size))
+    x = np.clip(x, 0.5, 1.9)
+    g0, g12 = gpu(gpu_ctx, "POW3_SHARED", x, y, two=True)
+    h0, h12 = cpu(host, "pow3_shared", x, y, outs=2)
+    same(g0, h0, "shared-row pow, centre")
+    same(g12, h12, "shared-row pow, outer points")
+    same(g0, gpu(gpu_ctx, "POW", x, y), "shared-row pow against the plain device pow")
 
 
 def test_dm_sqrt_inrange_is_ieee_sqrt_in_range(gpu_ctx, host):

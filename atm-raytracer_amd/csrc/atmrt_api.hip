@@ -541,6 +541,7 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   Frame f{};
   f.p = p;
   f.earth = c->earth;
+  f.inv_shape_radius = c->earth.spherical && c->earth.shape_radius != 0.0 ? 1.0 / c->earth.shape_radius : 0.0;
   HIP_TRY(c, c->d_atm.reserve(c->atm.bytes()));
   HIP_TRY(c, hipMemcpy(c->d_atm.ptr, &c->atm.table(), c->atm.bytes(), hipMemcpyHostToDevice));
   f.atm = c->d_atm.as<AtmTable>();

@@ -1309,13 +1309,15 @@ ATMRT_HD bool calc_dist_in_band(const AtmTable& atm, double h) {
   return h >= atm.alt_lo && h <= atm.alt_hi;
 #endif
 }
-ATMRT_HD double calc_dist(bool spherical, double radius, double x0, double h0, double x1, double h1, bool fast) {
+// rradius: RN(1 / radius), tabulated by the host (Frame::inv_shape_radius), or 0: the quotient dx / radius then comes from dm_div_r's
+// two corrections of dx * rradius instead of dm_div's v_rcp_f64 and Newton steps — the same IEEE quotient, six issue slots fewer.
+ATMRT_HD double calc_dist(bool spherical, double radius, double x0, double h0, double x1, double h1, bool fast, double rradius = 0.0) {
   double dx = x1 - x0;
   double dh = h1 - h0;
   if (fast) {
     if (!spherical) return dm_sqrt_inrange(dx * dx + dh * dh);
     double avg_h = (h1 + h0) / 2.0;
-    double dx2 = dm_div(dx, radius) * (avg_h + radius);
+    double dx2 = (rradius != 0.0 ? dm_div_r(dx, radius, rradius) : dm_div(dx, radius)) * (avg_h + radius);
     return dm_sqrt_inrange(dx2 * dx2 + dh * dh);
   }
   if (!spherical) return dm_sqrt(dx * dx + dh * dh);

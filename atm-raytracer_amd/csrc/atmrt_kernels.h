@@ -32,6 +32,7 @@ struct Frame {
   int32_t atm_cubic;        // the atmosphere has Spline segments: launch the kernel variants that carry the quadrature path
   int32_t di0, ei0;
   double dir_step, elev_step;
+  double inv_shape_radius;  // RN(1 / earth.shape_radius) (0 on a flat earth): calc_dist divides the step length by the radius (dm_div_r)
 };
 
 // column azimuth / row elevation in degrees, as handed to gen_terrain_cache / gen_path_cache

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
         bool tame;
         RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
         if (straight) tame = __all(calc_dist_in_band(*f.atm, sh) && calc_dist_in_band(*f.atm, st.h));
-        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h, tame);
+        path_length += calc_dist(sph, radius, sx, sh, st.x, st.h, tame, f.inv_shape_radius);
         sx = st.x;
         sh = st.h;
         if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)
@@ -402,7 +402,7 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
     bool tame;
     RayState nx = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
     if (straight) tame = __all(calc_dist_in_band(*f.atm, sh) && calc_dist_in_band(*f.atm, nx.h));
-    path_length += calc_dist(sph, radius, sx, sh, nx.x, nx.h, tame);
+    path_length += calc_dist(sph, radius, sx, sh, nx.x, nx.h, tame, f.inv_shape_radius);
     sx = nx.x;
     sh = nx.h;
     if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) return false; // rectilinear.rs:178 (+ NaN guard)
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
         bool tame;
         RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
         if (straight) tame = __all(calc_dist_in_band(*f.atm, sh_) && calc_dist_in_band(*f.atm, st.h));
-        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h, tame);
+        path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h, tame, f.inv_shape_radius);
         sx = st.x;
         sh_ = st.h;
         if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) break; // rectilinear.rs:178 (+ NaN guard)

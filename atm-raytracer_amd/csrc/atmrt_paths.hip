@@ -67,8 +67,13 @@ struct OctetRK4 {
   // k_1a is the start state and each later slope comes from exact earlier stages, so if all four pass all four stages were exact.
   // Otherwise (a wavefront straddling a layer boundary for a few steps; a pathological atmosphere) the step is thrown away and
   // repeated by the serial stepper with its per-stage guards.  One vote per step on this kernel's dependent chain.
+  // `idle`: this lane's row has finished — it takes part in the shuffles, its results are thrown away and its certificate does not
+  // count in the vote (left to run, a ray that ended below -1000 m keeps descending and leaves the certified part of the lowest
+  // layer a few steps later: from then on every step of its whole wavefront would fail the vote and be repeated serially).  What
+  // an idle lane computes outside a certified interval is garbage of no consequence: every table index is masked, atm_layer maps
+  // NaN to layer 0.
   __device__ __forceinline__ RayState next(Stepper& s, AtmLayerCache& cache, bool spherical, double radius, bool straight, double step,
-                                           bool& tame) const {
+                                           bool idle, bool& tame) const {
     if (straight) return stepper_next_with(s, spherical, radius, true, step, SerialAccel<CUBIC>{atm}, tame);
     const double d = spherical ? step / radius : step;
     const double half = 0.5 * d, sixth = d / 6.0;
@@ -88,7 +93,7 @@ struct OctetRK4 {
     const double k4b = accel(spherical, a + d * k3a, k4a, n4, dn4);
     const bool slopes_ok = !(dm_fabs(k1a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k2a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k3a) > ACCEL_FAST_MAX_B) &&
                            !(dm_fabs(k4a) > ACCEL_FAST_MAX_B);
-    if (!__all(slopes_ok && cert12 && cert34)) {
+    if (!__all(idle || (slopes_ok && cert12 && cert34))) {
       s.hint = hint0;
       return stepper_next_with(s, spherical, radius, false, step, SerialAccel<CUBIC>{atm}, tame);
     }
@@ -161,15 +166,9 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   AtmLayerCache cache; // the hinted layer's parameters, wave-uniform, read again only when the layer changes
   for (int i = i_begin; i < i_last; i++) {
     bool tame;
-    // A row that has finished takes part in every shuffle but does not move on: it repeats its last step.  (Left to run, a ray that
-    // ended below -1000 m keeps descending, leaves the certified part of the lowest layer a few steps later — and from then on every
-    // step of its whole wavefront fails the vote and is repeated by the serial stepper.)
-    const Stepper s_before = s;
-    const bool was_done = done;
-    RayState st = rk4.next(s, cache, sph, radius, straight, step, tame);
-    if (was_done) s = s_before;
+    RayState st = rk4.next(s, cache, sph, radius, straight, step, done, tame);
     if (straight) tame = __all(calc_dist_in_band(*f.atm, ph) && calc_dist_in_band(*f.atm, st.h));
-    path_length += calc_dist(sph, radius, px, ph, st.x, st.h, tame);
+    path_length += calc_dist(sph, radius, px, ph, st.x, st.h, tame, f.inv_shape_radius);
     if (!done) {
       if (writer) {
         pelev[base + n] = st.h;
@@ -181,10 +180,8 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
         n_final = n;
       }
     }
-    if (!was_done) { // (a finished row keeps repeating the one step after its last)
-      px = st.x;
-      ph = st.h;
-    }
+    px = st.x;
+    ph = st.h;
     if (__all(done)) break;
   }
   if (writer) {

@@ -515,7 +515,10 @@ static int prepare_frame(atmrt_ctx* c, Frame* out) {
   if (atm_compile(c->atm_def.pod, p.wavelength, c->atm)) return c->fail(ATMRT_ERR_INVALID_ARGUMENT, "invalid atmosphere");
   atm_certify(c->atm.table(), c->earth.spherical != 0, c->earth.shape_radius, p.simulation_step);
   if (getenv("ATMRT_NO_TIGHT")) // experiments: the voting path of dm_div3 on every segment (same bits, tests/test_gpu_march_variants.py)
-    for (int k = 0; k < c->atm.table().n; k++) c->atm.table().seg(k).flags &= ~ATM_SEG_TIGHT;
+    for (int k = 0; k < c->atm.table().n; k++) {
+      c->atm.table().seg(k).flags &= ~ATM_SEG_TIGHT;
+      c->atm.table().seg(k).tight_lo = INFINITY, c->atm.table().seg(k).tight_hi = -INFINITY;
+    }
   pinhole_init(p, c->pinhole);
   if (c->xs_dirty) {
     // distance table by repeated addition, exactly like `distance += step` (utils.rs:191-196) and the

@@ -48,7 +48,7 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // dh = h - hb.  Linear segments (cubic == 0) use the closed-form hydrostatic pressure, cubic ones a 5-point
 // Gauss-Legendre quadrature of dh/T.
 // Any number of segments (the reference's AtmosphereDef holds `Vec`s: README.md:283-323, params.rs:453-454): the table is a
-// 32-byte header followed, in the same allocation, by its n segments — one 104-byte record each, so the parameters of the
+// 32-byte header followed, in the same allocation, by its n segments — one 120-byte record each, so the parameters of the
 // wave-uniform hinted layer are one run of scalar loads and a per-lane layer is one gather base.
 struct AtmSeg {
   double hb;    // reference altitude of the segment
@@ -75,6 +75,9 @@ struct AtmSeg {
   // points of one right-hand side — dm_exp3_main_shared shares its table row among them while the centre's product is at most
   // this far from an integer (negative: never)
   double exp_thr;
+  // the TIGHT part [tight_lo, tight_hi) of the certified interval (empty: lo = +inf): the kernels vote on it first — the votes of
+  // dm_div3 and the v_rcp_f64 of Z and n go — and on [safe_lo, safe_hi) only when a lane is outside it
+  double tight_lo, tight_hi;
 };
 constexpr int32_t ATM_SEG_ISOTHERMAL = 1, ATM_SEG_TIGHT = 2;
 struct AtmTable {
@@ -85,7 +88,7 @@ struct AtmTable {
   ATMRT_HD const AtmSeg& seg(int k) const { return reinterpret_cast<const AtmSeg*>(this + 1)[k]; }
   ATMRT_HD AtmSeg& seg(int k) { return reinterpret_cast<AtmSeg*>(this + 1)[k]; }
 };
-static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 104, "device and host read the table as header + records");
+static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 120, "device and host read the table as header + records");
 // the table in the constant address space (it is read-only for a whole launch): wave-uniform indices become scalar loads
 #if defined(__HIPCC__)
 typedef const __attribute__((address_space(4))) AtmTable* AtmConstTable;
@@ -450,8 +453,8 @@ inline bool atm_interval_tight(const AtmTable& t, int k, double lo, double hi) {
 // or a refractivity constant outside 1e-12 .. 1e-3 (a wavelength on a resonance of the dispersion formula).
 inline void atm_certify(AtmTable& t, bool spherical, double radius, double step) {
   for (int k = 0; k < t.n; k++) {
-    t.seg(k).safe_lo = dm_inf();
-    t.seg(k).safe_hi = -dm_inf();
+    t.seg(k).safe_lo = t.seg(k).tight_lo = dm_inf();
+    t.seg(k).safe_hi = t.seg(k).tight_hi = -dm_inf();
     t.seg(k).flags = !t.seg(k).cubic && t.seg(k).lapse == 0.0 ? ATM_SEG_ISOTHERMAL : 0;
     // the exponents of the three points of one right-hand side: e = expo log(T / tb), log arguments within 2^-21 of one another on
     // a tight segment (+ the rounding of log itself: 4 ulp of a value below 12), or e = expo (h - hb) with h 1 cm apart
@@ -512,17 +515,28 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
     }
     t.seg(k).safe_lo = lo;
     t.seg(k).safe_hi = hi;
-    // Tight where the whole certified interval is.  Failing that, where its part between -1500 m and 100 km is — no ray marches
-    // below -1000 m (rectilinear.rs:178) and the layers of a physical atmosphere are certified tens of kilometres further down
-    // (and up: to where an extrapolated temperature reaches 1 K) than they are tight — keeping whatever of the rest is tight too;
-    // outside the cut the segment's evaluations take the IEEE operations.
-    const double cut_lo = lo > -1500.0 ? lo : -1500.0, cut_hi = hi < 1.0e5 ? hi : 1.0e5;
+    // The tight part of the certified interval: all of it, or — the lowest layer of a physical atmosphere is certified tens of
+    // kilometres further down than it is tight, the highest up to where its extrapolated temperature reaches 1 K and tight while it
+    // is above ~40 K — from -1500 m (or the interval's lower end) upwards as far as the bounds hold, found by bisection.  Rays
+    // march between -1000 m (rectilinear.rs:178) and a few tens of kilometres; a lane outside the tight part costs its wavefront
+    // the votes of dm_div3 and three v_rcp_f64 for that stage, nothing else.
+    const double cut_lo = lo > -1500.0 ? lo : -1500.0;
     if (atm_interval_tight(t, k, lo, hi)) {
+      t.seg(k).tight_lo = lo, t.seg(k).tight_hi = hi;
       t.seg(k).flags |= ATM_SEG_TIGHT;
-    } else if (cut_lo < cut_hi && atm_interval_tight(t, k, cut_lo, cut_hi)) {
-      if (atm_interval_tight(t, k, lo, cut_hi)) t.seg(k).safe_hi = cut_hi;
-      else if (atm_interval_tight(t, k, cut_lo, hi)) t.seg(k).safe_lo = cut_lo;
-      else t.seg(k).safe_lo = cut_lo, t.seg(k).safe_hi = cut_hi;
+    } else if (cut_lo < hi && atm_interval_tight(t, k, cut_lo, cut_lo + 1.0 < hi ? cut_lo + 1.0 : hi)) {
+      const double tl = atm_interval_tight(t, k, lo, cut_lo + 1.0 < hi ? cut_lo + 1.0 : hi) ? lo : cut_lo;
+      double good = cut_lo + 1.0 < hi ? cut_lo + 1.0 : hi, bad = hi;
+      if (atm_interval_tight(t, k, tl, hi)) {
+        good = hi;
+      } else {
+        for (int it = 0; it < 48; it++) {
+          const double mid = 0.5 * (good + bad);
+          if (atm_interval_tight(t, k, tl, mid)) good = mid;
+          else bad = mid;
+        }
+      }
+      t.seg(k).tight_lo = tl, t.seg(k).tight_hi = good;
       t.seg(k).flags |= ATM_SEG_TIGHT;
     }
   }
@@ -761,7 +775,8 @@ struct AtmLayerCache {
   double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
 };
 template <bool CUBIC>
-__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified) {
+__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified,
+                                                     bool idle = false) {
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   if (ku != cache.k) { // wave-uniform
     const AtmConstSeg ks = atm_const_seg(a, ku);
@@ -771,7 +786,7 @@ __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayer
     cache.lapse = ks->lapse, cache.c2 = ks->c2, cache.c3 = ks->c3, cache.expo = ks->expo;
     cache.k_refr = atm_const_table(a)->k_refr;
   }
-  if (__all(h >= cache.safe_lo && h < cache.safe_hi)) {
+  if (__all(idle || (h >= cache.safe_lo && h < cache.safe_hi))) { // (an idle lane's value is discarded: it does not vote)
     certified = true;
     return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
   }
@@ -796,9 +811,10 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
   const AtmConstTable ka = atm_const_table(a);
   const AtmConstSeg ks = atm_const_seg(a, ku);
-  if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
+  const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi);
+  if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
     const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
-    const int cubic = ks->cubic, flags = ks->flags;
+    const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n1, n2, q0;
     refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
@@ -1207,9 +1223,12 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
   const AtmConstTable ka = atm_const_table(atm);
   const AtmConstSeg ks = atm_const_seg(atm, ku);
-  if (__all(h1 >= ks->safe_lo && h2 < ks->safe_hi && !(dm_fabs(b) > ACCEL_FAST_MAX_B))) {
+  // the tight part of the hinted layer first (one vote: the normal case), its whole certified part when a lane is outside that
+  const bool slope_ok = !(dm_fabs(b) > ACCEL_FAST_MAX_B);
+  const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi && slope_ok);
+  if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi && slope_ok)) {
     const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
-    const int cubic = ks->cubic, flags = ks->flags;
+    const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n, n1, n2, q0;
     refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);

@@ -38,13 +38,13 @@ struct OctetRK4 {
 
   // n and dn at position `pos` for both stage groups: this lane evaluates its share, everyone receives both results
   __device__ __forceinline__ void eval(bool spherical, double radius, double pos_a, double pos_b, int& hint, AtmLayerCache& cache,
-                                       double& n_a, double& dn_a, double& n_b, double& dn_b, bool& certified) const {
+                                       double& n_a, double& dn_a, double& n_b, double& dn_b, bool& certified, bool idle) const {
     const double eps = 0.01;
     const double pos = (sub & 4) ? pos_b : pos_a;
     const double h = spherical ? pos - radius : pos;
     const int e = sub & 3;
     const double hh = e == 1 ? h - eps : e == 2 ? h + eps : h;
-    const double nv = refr_n_speculative<CUBIC>(atm, cache, hh, hint, certified);
+    const double nv = refr_n_speculative<CUBIC>(atm, cache, hh, hint, certified, idle);
     // every lane of a quad: its quad's n(h), n(h - eps), n(h + eps); then dn for the quad's stage, then the other quad's pair
     const double n_q = dpp_move<DPP_QUAD_BCAST0>(nv);
     const double q1 = dpp_move<DPP_QUAD_BCAST1>(nv), q2 = dpp_move<DPP_QUAD_BCAST2>(nv);
@@ -82,12 +82,12 @@ struct OctetRK4 {
     double n1, dn1, n2, dn2, n3, dn3, n4, dn4;
     bool cert12, cert34; // per lane
     const double k1a = b;
-    eval(spherical, radius, a, a + half * k1a, s.hint, cache, n1, dn1, n2, dn2, cert12);
+    eval(spherical, radius, a, a + half * k1a, s.hint, cache, n1, dn1, n2, dn2, cert12, idle);
     const double k1b = accel(spherical, a, b, n1, dn1);
     const double k2a = b + half * k1b;
     const double k2b = accel(spherical, a + half * k1a, k2a, n2, dn2);
     const double k3a = b + half * k2b;
-    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, cache, n3, dn3, n4, dn4, cert34);
+    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, cache, n3, dn3, n4, dn4, cert34, idle);
     const double k3b = accel(spherical, a + half * k2a, k3a, n3, dn3);
     const double k4a = b + d * k3b;
     const double k4b = accel(spherical, a + d * k3a, k4a, n4, dn4);

@@ -34,7 +34,7 @@ int ch_cart(const atmrt_earth_model_t* m, double lat, double lon, double elev, d
 // of the certificate: min T, max p/T, max |Z - 1| and max n over a dense sample of the interval
 int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, double radius, double step, int* n_seg, double* from,
                double* safe_lo, double* safe_hi, double* band2, double* min_t, double* max_pt, double* max_z_dev, double* max_n,
-               double* max_abs_e, double* flags, double* max_dt_rel, double* max_dz_rel) {
+               double* max_abs_e, double* flags, double* max_dt_rel, double* max_dz_rel, double* tight_lo, double* tight_hi, double* tight_max_q, double* tight_max_zdev) {
   AtmTableBuf buf;
   if (atm_compile(*def, wavelength, buf)) return -1;
   AtmTable& a = buf.table();
@@ -48,6 +48,9 @@ int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, 
     safe_hi[k] = a.seg(k).safe_hi;
     min_t[k] = 1e300; max_pt[k] = max_z_dev[k] = max_n[k] = max_abs_e[k] = max_dt_rel[k] = max_dz_rel[k] = 0.0;
     flags[k] = (double)a.seg(k).flags;
+    tight_lo[k] = a.seg(k).tight_lo;
+    tight_hi[k] = a.seg(k).tight_hi;
+    tight_max_q[k] = tight_max_zdev[k] = 0.0;
     if (!(a.seg(k).safe_lo < a.seg(k).safe_hi)) continue;
     const int N = 4000;
     for (int i = 0; i <= N; i++) {
@@ -60,8 +63,12 @@ int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, 
       double zd = z > 1.0 ? z - 1.0 : 1.0 - z;
       if (!(zd <= max_z_dev[k])) max_z_dev[k] = zd;
       if (!(n <= max_n[k])) max_n[k] = n;
+      if (h >= a.seg(k).tight_lo && h < a.seg(k).tight_hi) {
+        if (!(n - 1.0 <= tight_max_q[k])) tight_max_q[k] = n - 1.0;
+        if (!(zd <= tight_max_zdev[k])) tight_max_zdev[k] = zd;
+      }
       // what a TIGHT segment promises about the three points of one right-hand side, h and h -+ 1 cm (atm_interval_tight)
-      for (int sgn = -1; sgn <= 1; sgn += 2) {
+      for (int sgn = -1; sgn <= 1 && h >= a.seg(k).tight_lo && h < a.seg(k).tight_hi; sgn += 2) {
         const double h2 = h + sgn * 0.01, t2 = atm_seg_temperature(a, k, h2), pt2 = a.seg(k).pb * atm_pressure_ratio(a, k, h2) / t2, c2 = t2 - 273.15;
         const double z2 = 1.0 - pt2 * (1.58123e-6 + c2 * (-2.9331e-8 + c2 * 1.1043e-10)) + pt2 * pt2 * 1.83e-11;
         const double dt = t2 / t - 1.0, dz = z2 / z - 1.0;

@@ -107,12 +107,13 @@ WILD_SPLINE = {"pressure": {"altitude": 0.0, "pressure": 102390.63927278577},
 def _certify(core, atm, spherical=True, radius=6371000.0, step=50.0, wavelength=530e-9):
     n = C.c_int(0)
     cap = sum(atm.functions[j].n_points + 1 if atm.functions[j].kind == 1 else 1 for j in range(atm.n_functions))  # most segments the table can have
-    arrs = [np.zeros(cap) for _ in range(11)]
+    arrs = [np.zeros(cap) for _ in range(15)]
     band = np.zeros(2)
     assert core.ch_certify(C.byref(atm), C.c_double(wavelength), int(spherical), C.c_double(radius), C.c_double(step), C.byref(n),
                            ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(band), ptr(arrs[3]), ptr(arrs[4]), ptr(arrs[5]), ptr(arrs[6]), ptr(arrs[7]),
-                           ptr(arrs[8]), ptr(arrs[9]), ptr(arrs[10])) == 0
-    keys = ("from", "safe_lo", "safe_hi", "min_t", "max_pt", "max_z_dev", "max_n", "max_abs_e", "flags", "max_dt_rel", "max_dz_rel")
+                           ptr(arrs[8]), ptr(arrs[9]), ptr(arrs[10]), ptr(arrs[11]), ptr(arrs[12]), ptr(arrs[13]), ptr(arrs[14])) == 0
+    keys = ("from", "safe_lo", "safe_hi", "min_t", "max_pt", "max_z_dev", "max_n", "max_abs_e", "flags", "max_dt_rel", "max_dz_rel", "tight_lo",
+            "tight_hi", "tight_max_q", "tight_max_zdev")
     return {k: a[:n.value] for k, a in zip(keys, arrs)}, band
 
 
@@ -124,20 +125,23 @@ def test_certified_intervals_cover_the_standard_atmosphere(core):
     c, band = _certify(core, config.us76())
     bounds = [11000.0, 20000.0, 32000.0, 47000.0, 51000.0, 71000.0]
     assert list(c["safe_hi"][:6]) == bounds and list(c["safe_lo"][1:]) == bounds
-    # Round 4: every layer of the standard atmosphere is TIGHT (flag 2; flag 1 marks the isothermal ones) — the kernels' three-point
-    # divisions run without votes and with seeded reciprocals there.  The lowest layer is certified down to -47 km but tight only
-    # above -1500 m (no ray marches below -1000 m), the highest up to 178 km (where its extrapolated temperature reaches 1 K) but
-    # tight only while T is above ~40 K: their intervals are cut at -1500 m and 100 km.
-    assert [int(f) for f in c["flags"]] == [2, 3, 2, 2, 3, 2, 2] and c["safe_lo"][0] == -1500.0 and c["safe_hi"][6] == 100000.0
+    assert -60000.0 < c["safe_lo"][0] < -30000.0 and 170000.0 < c["safe_hi"][6] < 180000.0
+    # Round 4: every layer of the standard atmosphere has a TIGHT part (flag 2; flag 1 marks the isothermal ones) on which the
+    # kernels' three-point divisions run without votes and with seeded reciprocals: the whole certified interval of the middle
+    # layers; the lowest layer (certified down to -47 km) from -1500 m up — no ray marches below -1000 m —, the highest (certified up
+    # to 178 km, where its extrapolated temperature reaches 1 K) while T is above ~40 K, to ~157 km.
+    assert [int(f) for f in c["flags"]] == [2, 3, 2, 2, 3, 2, 2]
+    assert list(c["tight_lo"][1:]) == bounds and list(c["tight_hi"][:6]) == bounds
+    assert c["tight_lo"][0] == -1500.0 and 150000.0 < c["tight_hi"][6] < 160000.0
     assert c["max_dt_rel"].max() <= 2.0 ** -21 and c["max_dz_rel"].max() <= 2.0 ** -21
-    assert c["max_n"].max() - 1.0 <= 2.0 ** -10.5 and c["max_z_dev"].max() <= 2.0 ** -10.5
+    assert c["tight_max_q"].max() <= 2.0 ** -10.5 and c["tight_max_zdev"].max() <= 2.0 ** -10.5
     # a polar-winter surface layer (-40 C at 1040 hPa): certified as before, not tight (|1 - Z| = 1.3e-3) — the voting path serves it
     cold = config.Config.from_dict({"atmosphere": {"pressure": {"altitude": 0.0, "pressure": 104000.0},
                                                    "temperature_fixed_point": {"altitude": 0.0, "temperature": 233.15},
                                                    "first_temperature_function": {"Linear": {"gradient": 0.002}}},
                                     "output": {"width": 8, "height": 8}})
     cc, _ = _certify(core, cold.atmosphere)
-    assert int(cc["flags"][0]) == 0 and cc["safe_lo"][0] < 1.0 < 1000.0 < cc["safe_hi"][0] and cc["max_z_dev"][0] > 2.0 ** -10.5
+    assert int(cc["flags"][0]) == 0 and cc["tight_lo"][0] == np.inf and cc["safe_lo"][0] < 1.0 < 1000.0 < cc["safe_hi"][0] and cc["max_z_dev"][0] > 2.0 ** -10.5
     assert band[0] == -100000.0 and band[1] == 1.0e7
     # an independent dense sample of the certified intervals stays far inside the shortcuts' range
     assert c["min_t"].min() >= 1.0 and c["max_z_dev"].max() <= 0.5 and c["max_n"].max() < 2.0 and c["max_pt"].max() < 2.0e5
@@ -213,7 +217,8 @@ def test_certificates_of_random_atmospheres_hold_on_a_dense_sample(core, block):
             if int(c["flags"][k]) & 2:  # a tight segment keeps its promises on the dense sample too
                 n_tight[0] += 1
                 assert c["max_dt_rel"][k] <= 2.0 ** -21 * 1.001 and c["max_dz_rel"][k] <= 2.0 ** -21 * 1.001, (atm, k)
-                assert c["max_n"][k] - 1.0 <= 2.0 ** -10.5 and c["max_z_dev"][k] <= 2.0 ** -10.5, (atm, k)
+                assert c["tight_max_q"][k] <= 2.0 ** -10.5 and c["tight_max_zdev"][k] <= 2.0 ** -10.5, (atm, k)
+                assert c["safe_lo"][k] <= c["tight_lo"][k] < c["tight_hi"][k] <= c["safe_hi"][k], (atm, k)
             assert band[0] <= c["safe_lo"][k] and c["safe_hi"][k] <= band[1]
             if k > 0:
                 assert c["safe_lo"][k] >= c["from"][k]

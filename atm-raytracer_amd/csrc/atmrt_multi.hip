@@ -255,12 +255,22 @@ struct MultiGroup {
   }
 };
 
+// Equal tiles, their inner boundaries on multiples of 64 columns when every tile is at least 128 wide (tiles_rebalance below says
+// why: a wavefront then is 64 adjacent columns of one row; a 500-column tile marches 15 % slower than a 512-column one, which is
+// more than the 64 columns of imbalance the alignment can cost).  Widths that divide evenly into multiples of 64 — 4096 or 8192
+// over 2, 4, 8 ranks — are cut exactly as g W / G.
+static int tile_begin_aligned(int width, int g, int world) {
+  const int b = shard_begin(width, g, world);
+  if (g == 0 || g == world || width < 128 * world) return b;
+  return (b + 32) / 64 * 64;
+}
+
 // The tiling the next frame of a `width`-column image uses: equal widths whenever the width (or nothing yet) says so.
 static void comm_tiling(Comm* cm, int width) {
   const int G = cm->world;
   if (cm->cols_W == width && (int)cm->cols.size() == G + 1) return;
   cm->cols.resize((size_t)G + 1);
-  for (int g = 0; g <= G; g++) cm->cols[(size_t)g] = shard_begin(width, g, G);
+  for (int g = 0; g <= G; g++) cm->cols[(size_t)g] = tile_begin_aligned(width, g, G);
   cm->cols_W = width;
   cm->cols_pinned = false;
 }
@@ -273,28 +283,53 @@ void comm_columns(const atmrt_ctx* c, int width, int* c0, int* c1) {
 }
 
 // Tile boundaries that would have equalised the tiles' times, had the cost per column been constant inside each tile: the inverse
-// of the piecewise-linear cumulative cost at k / G of its total.  A pure function of its arguments — every rank evaluates it on
-// the same gathered numbers and gets the same tiling.  Widths stay >= 1.  Returns false (and copies the input) when a time is
-// not a positive finite number.
-bool tiles_rebalance(int W, int G, const int* cols, const double* ms, int* out) {
+// of the piecewise-linear cumulative cost at k / G of its total — moved to the nearest multiple of 64 columns.  A wavefront of the
+// marching kernels is 64 consecutive pixels of the tile's row-major order: with a width that is a multiple of 64 it is 64 adjacent
+// columns of ONE row (rays that leave the terrain's height range and end together); with any other width most wavefronts straddle
+// two rows, i.e. both edges of the tile, and the march of the headline's tiles takes 15 % longer (measured, round 4:
+// profiles/r04/shard_balance_unquantised_recut.json — 8 x 30.2 ms with 512-column tiles, 8 x 34.8 ms with 490 .. 559).  Images
+// narrower than 128 columns per tile are cut to the column (nothing to keep aligned).  The re-cut is adopted only if, under the
+// same model, it shortens the slowest tile by at least 1 %.  A pure function of its arguments — every rank evaluates it on the same
+// gathered numbers and gets the same tiling.  Widths stay >= 1.  Returns false (and copies the input) when a time is not a positive
+// finite number or nothing is to be gained.
+// returns 1: a new cut, 0: the tiling stays (nothing to gain), -1: invalid input
+int tiles_rebalance(int W, int G, const int* cols, const double* ms, int* out) {
   for (int g = 0; g <= G; g++) out[g] = cols[g];
-  double total = 0.0;
+  double total = 0.0, worst = 0.0;
   for (int g = 0; g < G; g++) {
-    if (!(ms[g] > 0.0) || !(ms[g] < 1e300) || cols[g + 1] <= cols[g]) return false;
+    if (!(ms[g] > 0.0) || !(ms[g] < 1e300) || cols[g + 1] <= cols[g]) return -1;
     total += ms[g];
+    worst = std::max(worst, ms[g]);
   }
-  if (cols[0] != 0 || cols[G] != W) return false;
+  if (cols[0] != 0 || cols[G] != W) return -1;
+  const int q = W >= 128 * G ? 64 : 1; // the quantum of a boundary
+  std::vector<int> next((size_t)G + 1);
+  next[0] = 0, next[(size_t)G] = W;
   int g = 0;
   double before = 0.0; // cost of the tiles left of tile g
   for (int k = 1; k < G; k++) {
     const double want = total * (double)k / (double)G;
     while (g < G - 1 && before + ms[g] < want) before += ms[g], g++;
     const double x = (double)cols[g] + (want - before) / ms[g] * (double)(cols[g + 1] - cols[g]);
-    out[k] = (int)(x + 0.5);
+    next[(size_t)k] = (int)(x / q + 0.5) * q;
   }
-  for (int k = 1; k < G; k++) out[k] = std::max(out[k], out[k - 1] + 1);
-  for (int k = G - 1; k >= 1; k--) out[k] = std::min(out[k], out[k + 1] - 1);
-  return true;
+  for (int k = 1; k < G; k++) next[(size_t)k] = std::max(next[(size_t)k], next[(size_t)k - 1] + q);
+  for (int k = G - 1; k >= 1; k--) next[(size_t)k] = std::min(next[(size_t)k], next[(size_t)k + 1] - (k + 1 == G ? 1 : q));
+  for (int k = 1; k <= G; k++)
+    if (next[(size_t)k] <= next[(size_t)k - 1]) return 0; // (cannot happen for W >= G; guards the arithmetic above)
+  // the slowest tile of the new cut under the model: cost of [a, b) = sum over old tiles of their density x overlap
+  double new_worst = 0.0;
+  for (int k = 0; k < G; k++) {
+    double cost = 0.0;
+    for (int j = 0; j < G; j++) {
+      const int lo = std::max(next[(size_t)k], cols[j]), hi = std::min(next[(size_t)k + 1], cols[j + 1]);
+      if (hi > lo) cost += ms[j] * (double)(hi - lo) / (double)(cols[j + 1] - cols[j]);
+    }
+    new_worst = std::max(new_worst, cost);
+  }
+  if (!(new_worst <= 0.99 * worst)) return 0;
+  for (int k = 0; k <= G; k++) out[k] = next[(size_t)k];
+  return 1;
 }
 
 int multi_size(const atmrt_ctx* parent) { return parent->multi ? (int)parent->multi->kids.size() : 1; }
@@ -620,7 +655,7 @@ void tile_rebalance(Comm* cm) {
   }
   if (!(sum > 0.0) || !(worst * G > 1.01 * sum)) return; // balanced within 1 %: leave it (the times carry that much noise)
   std::vector<int> next((size_t)G + 1);
-  if (tiles_rebalance(cm->W, G, cm->cols_frame.data(), ms.data(), next.data())) cm->cols = next;
+  if (tiles_rebalance(cm->W, G, cm->cols_frame.data(), ms.data(), next.data()) == 1) cm->cols = next;
 }
 
 // Phase B: the collective + the permutation into `image` (planes on this rank's device; NULL azimuth: take part, assemble nothing).
@@ -1139,7 +1174,7 @@ extern "C" int atmrt_ctx_tile_columns(atmrt_ctx* c, int32_t index, int32_t* col_
 
 extern "C" int atmrt_tiles_rebalance(int32_t width, int32_t n_tiles, const int32_t* cols, const double* tile_ms, int32_t* cols_out) {
   if (!cols || !tile_ms || !cols_out || n_tiles < 1 || width < n_tiles) return ATMRT_ERR_INVALID_ARGUMENT;
-  return tiles_rebalance(width, n_tiles, cols, tile_ms, cols_out) ? ATMRT_OK : ATMRT_ERR_INVALID_ARGUMENT;
+  return tiles_rebalance(width, n_tiles, cols, tile_ms, cols_out) >= 0 ? ATMRT_OK : ATMRT_ERR_INVALID_ARGUMENT;
 }
 
 extern "C" int atmrt_debug_set_tiling(atmrt_ctx* c, const int32_t* cols, int32_t n) {
@@ -1315,7 +1350,7 @@ int atmrt::multi_generate(atmrt_ctx* parent, atmrt_result_t* out) {
     double sum = 0.0;
     for (size_t i = 0; i < n; i++) sum += (tms[i] = g->kids[i]->timings.total_ms);
     std::vector<int> next(n + 1);
-    if (tm.tile_ms_max * (double)n > 1.01 * sum && tiles_rebalance(W, (int)n, c0m->cols.data(), tms.data(), next.data()))
+    if (tm.tile_ms_max * (double)n > 1.01 * sum && tiles_rebalance(W, (int)n, c0m->cols.data(), tms.data(), next.data()) == 1)
       for (atmrt_ctx* k : g->kids) k->comm->cols = next;
   }
   return ATMRT_OK;

@@ -415,13 +415,16 @@ int atmrt_last_comm_timings(atmrt_ctx* ctx, atmrt_comm_timings_t* out);
 int atmrt_comm_available(void);
 /* The pixel columns [*col_begin, *col_end) of a tile: of the last frame that was exchanged, else of the next one.  A multi-device
  * context: of device `index`; a rank context: of rank `index` (index < 0: its own); a plain context: its whole width or shard.
- * Tiles start equal (rank g of G: [g W / G, (g + 1) W / G)) and are RE-CUT by the library after a frame whose slowest tile took
+ * Tiles start equal (rank g of G: [g W / G, (g + 1) W / G), inner boundaries on multiples of 64 columns when tiles are at least 128
+ * wide) and are RE-CUT by the library after a frame whose slowest tile took
  * more than 1 % longer than the mean — every rank from the same gathered tile times, so all agree without a message
  * (ATMRT_TILE_BALANCE=0 keeps them equal; 1 forces re-cutting where it is off by default: devices listed twice, the host-buffer
  * transport). */
 int atmrt_ctx_tile_columns(atmrt_ctx* ctx, int32_t index, int32_t* col_begin, int32_t* col_end);
 /* The re-cutting rule itself, a pure function: cols (n_tiles + 1 ascending boundaries, 0 .. width) and each tile's time ->
- * boundaries that would have equalised the times had the cost per column been constant inside each tile. */
+ * boundaries that would have equalised the times had the cost per column been constant inside each tile, on multiples of 64 columns
+ * (a wavefront of the marching kernels is 64 consecutive pixels: tiles whose width is not a multiple of 64 march 15 % slower) when
+ * every tile is at least 128 wide; cols_out = cols when the re-cut would not shorten the slowest tile by 1 % under that model. */
 int atmrt_tiles_rebalance(int32_t width, int32_t n_tiles, const int32_t* cols, const double* tile_ms, int32_t* cols_out);
 /* Test hooks.  set_tiling: the next frames use exactly these n = world + 1 boundaries (NULL: back to the library's own); on a
  * rank context every rank must be given the same.  fail_next_collective: the nth data-path collective from now (1 = the next)

@@ -110,15 +110,21 @@ def test_tiles_rebalance_is_a_pure_deterministic_rule(lib):
     equal = [g * W // 8 for g in range(9)]
     rc, same = rebalance(W, equal, [33.0] * 8)
     assert rc == 0 and same == equal
-    # the last two tiles 5 % slower (the headline's low-sky columns): they get narrower, the others wider, total cost now level
-    ms = [32.2] * 6 + [33.7, 33.7]
+    # the last two tiles 5 % slower (the headline's low-sky columns): a boundary moves only in steps of 64 columns (a wavefront is 64
+    # adjacent pixels: unaligned tiles march 15 % slower), and 64 of 512 columns is more than 5 % — the tiling stays
+    rc, cols = rebalance(W, equal, [32.2] * 6 + [33.7, 33.7])
+    assert rc == 0 and cols == equal
+    # one tile twice as slow as the others: it gives columns away in multiples of 64, and the model's slowest tile gets faster
+    ms = [30.0] * 7 + [60.0]
     rc, cols = rebalance(W, equal, ms)
     assert rc == 0 and cols[0] == 0 and cols[-1] == W and all(b > a for a, b in zip(cols, cols[1:]))
-    widths = [b - a for a, b in zip(cols, cols[1:])]
-    assert widths[7] < 512 < widths[0] and widths[6] < 512
-    cost = [w * m / 512 for w, m in zip(widths, ms)]  # under the rule's own model: constant cost per column inside an old tile
-    assert max(cost) / (sum(cost) / 8) < 1.005, cost
+    assert all(c % 64 == 0 for c in cols) and cols[8] - cols[7] < 512 < cols[1] - cols[0]
+    cost = [sum(m * max(0, min(b, e1) - max(a, e0)) / 512 for m, e0, e1 in zip(ms, equal, equal[1:])) for a, b in zip(cols, cols[1:])]
+    assert max(cost) < 0.75 * max(ms), cost
     assert rebalance(W, equal, ms)[1] == cols  # deterministic
+    # narrow images (fewer than 128 columns per tile) are cut to the column
+    rc, cols = rebalance(400, [0, 100, 200, 300, 400], [10.0, 10.0, 10.0, 20.0])
+    assert rc == 0 and cols[0] == 0 and cols[-1] == 400 and cols[4] - cols[3] < 100 and any(c % 64 for c in cols)
     # one pathological tile
     rc, cols = rebalance(16, [0, 2, 4, 6, 8, 10, 12, 14, 16], [1.0] * 7 + [1000.0])
     assert rc == 0 and cols[0] == 0 and cols[-1] == 16 and all(b > a for a, b in zip(cols, cols[1:]))

@@ -156,7 +156,7 @@ class Timings(C.Structure):
 
 
 class FrameStats(C.Structure):
-    _fields_ = [(k, C.c_uint64) for k in ("unlisted_rays", "unlisted_columns", "retraced_pixels", "big_steps", "big_blend_pixels", "terrain_lookups", "object_rays")]
+    _fields_ = [(k, C.c_uint64) for k in ("unlisted_rays", "unlisted_columns", "retraced_pixels", "big_steps", "big_blend_pixels", "terrain_lookups", "object_rays", "object_steps")]
 
 
 def result_to_numpy(res):

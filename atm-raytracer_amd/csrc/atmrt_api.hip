@@ -668,6 +668,7 @@ static int prepare_workspace(atmrt_ctx* c, const Frame& f, Workspace* ws) {
   ws->list_pixel = nullptr;
   ws->step_prop = nullptr;
   ws->object_rays = nullptr;
+  ws->step_ctx = nullptr;
   ws->overflow_arena = nullptr;
   ws->overflow_cap = 0;
   ws->n_overflow_records = 0;
@@ -762,6 +763,8 @@ static int run_core(atmrt_ctx* c, const Frame& f, Workspace& ws, const DensePlan
     // lists them), then the tracer over that list
     HIP_TRY(c, c->d_object_rays.reserve((size_t)f.wl * f.h * sizeof(uint32_t)));
     ws.object_rays = c->d_object_rays.as<uint32_t>();
+    HIP_TRY(c, c->d_step_ctx.reserve((sizeof(Frame) + 255) / 256 * 256 + OBJECT_STEP_SINKS_MAX_BYTES));
+    ws.step_ctx = c->d_step_ctx.as<char>();
     HIP_TRY(c, hipEventRecord(ev[4], s));
     launch_trace_count(f, ws, dense, s);
     uint64_t cnt[N_COUNTERS] = {};
@@ -1033,6 +1036,7 @@ static int run_generator(atmrt_ctx* c, const Frame& f, Workspace& ws, const Dens
   c->stats.retraced_pixels += ws.n_overflow;
   c->stats.terrain_lookups = counters[10];
   c->stats.object_rays = counters[11];
+  c->stats.object_steps = counters[14];
   if (ms_out) *ms_out = ms;
   if (ray_steps_out) *ray_steps_out = counters[0];
   if (packed_out) *packed_out = packed;

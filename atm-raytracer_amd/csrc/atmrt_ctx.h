@@ -147,7 +147,7 @@ struct atmrt_ctx {
       d_list_step, d_list_pixel, d_rect_rec, d_dense, d_packed, d_io, d_objects, d_textures, d_plat, d_plon,
       d_ccount, d_coffset, d_clist, d_px_steps, d_atm, d_interp, d_lat_dense, d_lat_packed, d_lat_offset, d_slot_step, d_slot_rec,
       d_overflow, d_slot_pixel, d_slot_packed, d_pelev_t, d_plen_t, d_col_cand, d_col_ncand, d_path_seg, d_dprev, d_step_prop,
-      d_blend_arena, d_object_rays, d_col_lo, d_col_hi, d_traced, d_slice, d_overflow_arena;
+      d_blend_arena, d_object_rays, d_col_lo, d_col_hi, d_traced, d_slice, d_overflow_arena, d_step_ctx;
 
   int fail(int code, const char* fmt, ...) {
     char buf[1024];

@@ -376,4 +376,18 @@ static inline RectRec carve_rec(double* base, size_t n) {
   return r;
 }
 
+// where the out-of-line object step of the lean march (object_step_impl, atmrt_march_impl.h) writes: the general tracer's arenas of
+// the counting pass.  A copy lives in HBM beside a copy of the Frame (Workspace::step_ctx): an out-of-line device function cannot
+// address a kernel's by-value arguments.
+struct ObjectStepSinks {
+  PackedHits slot_packed;  // [plane * RECT_SLOTS]
+  RectRec slots;
+  uint32_t* slot_step;
+  uint32_t* slot_pixel;
+  OverflowArena ovf;
+  PackedHits ovf_packed;
+  unsigned long long* counters;
+};
+static_assert(sizeof(ObjectStepSinks) <= OBJECT_STEP_SINKS_MAX_BYTES, "Workspace::step_ctx reserves this much behind the Frame");
+
 } // namespace atmrt

@@ -86,7 +86,7 @@ struct PathSegState {
 // [7] InterpolatingRectilinear pixels with more corner points than the in-register member list, [8] their corner points
 // together (size of the member arena), [9] cursor of that arena, [10] terrain lookups performed by the Rectilinear march,
 // [11] rays of a scene with objects that the lean march left to the general tracer
-constexpr int N_COUNTERS = 14; // [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks); [13]: records appended to the overflow arena
+constexpr int N_COUNTERS = 16; // [14]: ray-steps handed to the lean march's out-of-line object step; [12]: groups the time-sliced march left unfinished (must be 0: atmrt_api.hip checks); [13]: records appended to the overflow arena
 
 // Scratch owned by the context, sized for the current frame.
 // crossings per pixel recorded by the counting march (4096x2048 headline at terrain_alpha 0.5: 99.3 % of the pixels have <= 4)
@@ -105,6 +105,7 @@ struct OverflowArena {
   uint32_t* color_tag; // scenes with objects: the PackedHits arena's tags (the lean march writes TERRAIN), else null
   uint32_t cap;
 };
+constexpr size_t OBJECT_STEP_SINKS_MAX_BYTES = 1024; // ObjectStepSinks (atmrt_device.h) fits: what Workspace::step_ctx reserves behind the Frame
 static inline size_t overflow_arena_bytes(size_t cap) { return cap * (3 * sizeof(uint32_t) + 4 * sizeof(double)); }
 static inline OverflowArena carve_overflow(char* base, size_t cap) {
   OverflowArena a{};
@@ -194,6 +195,7 @@ struct Workspace {
   double* col_hi;
   uint8_t* traced;        // [h][wl] Fast with objects: 1 = the pixel can have a step with an object (k_fast_flag_rows)
   uint32_t* object_rays;  // Rectilinear, scenes with objects: pixels the lean march left to the general tracer
+  char* step_ctx;         // Rectilinear, scenes with objects: Frame + ObjectStepSinks in HBM for the lean march's out-of-line object step
   double* step_prop;      // fill pass, frames with big steps only: `prop` of every listed trace point (big_step_sort)
   uint32_t* px_steps;     // optional [h][wl]: ray-steps of each pixel (InterpolatingRectilinear counts referenced lattice pixels only)
   char* overflow_arena;   // Rectilinear, translucent terrain or objects: trace points beyond the slots (OverflowArena), or null

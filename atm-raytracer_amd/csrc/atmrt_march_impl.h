@@ -105,6 +105,96 @@ static __device__ __forceinline__ void overflow_append(const OverflowArena& ovf,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MODE 3, the rare step.  Until round 3 a ray of the lean march that reached a step which could involve an object was abandoned
+// there and traced again from x = 0 by the general tracer k_rect_trace — 11 % of config 5's rays, 38 ms of 333 for the frame and a
+// launch of under two wavefronts per SIMD for a column tile (12 ms at the speed of a lone wavefront's dependency chain whatever the
+// tile's size: config 5 did not strong-scale, 0.73 at 8 tiles).  Yet the steps that involve an object are a handful per such ray
+// (the step must lie inside an object's distance interval AND enter its height band): 0.05 % of all steps.  So the lean march now
+// keeps the ray and hands only THAT STEP to an out-of-line function that does what get_single_pixel does for a step in full
+// (utils.rs:211-285): both samples' geodesic points and terrain heights, the terrain crossing, the proximity filter of the two
+// samples over the wavefront's candidate objects (TerrainData::from_lat_lon, utils.rs:74-80), the collisions (frustum.rs:18-101,
+// billboard.rs), the stable sort by `prop`, the emission into the tracer's slot arena / overflow arena — the general tracer's own
+// building blocks (step_push, step_object_impl, step_emit), so the trace points are the tracer's to the bit.  The function is
+// called under divergent control flow a few times per flagged ray; it reads the frame and the sinks through pointers to copies in
+// HBM (a kernel argument cannot be addressed) and is built, like every unit that calls device functions, without interprocedural
+// register allocation (Makefile CALL_EXTRA).  Only a wavefront whose candidate list overflows (more than WAVE_CAND objects) or an
+// earth model without the geometric pre-filter still leaves its rays to k_rect_trace.
+struct ObjectStepIO {      // one lane's step, in scratch at the call site
+  DirCalc c;
+  double d0, sx, re0, sh, pl0, path_length; // the two samples: stepper x, ray elevation, path length
+  double diff1;            // out: ray - terrain at the newer sample (the next step's diff0)
+  uint32_t pixel;
+  int32_t step_index;      // of the older sample
+  unsigned count;          // in / out: trace points of the pixel so far
+  int32_t finish;          // out: the ray ends with this step (utils.rs:237-239, 274-285)
+};
+template <int CALC>
+static __device__ __attribute__((noinline)) void object_step_impl(const Frame* __restrict__ fg, const ObjectStepSinks* __restrict__ sk,
+                                                                  ObjectStepIO* io, const double* w_lo, const double* w_hi,
+                                                                  const int* w_obj, int n_e) {
+  Earth e = fg->earth;
+  e.calc = CALC;
+  const DirCalc& c = io->c;
+  const double d0 = io->d0, sx = io->sx, re0 = io->re0, sh = io->sh, pl0 = io->pl0, path_length = io->path_length;
+  double lat0, lon0, lat1, lon1;
+  coords_at_dist(e, c, d0, lat0, lon0);
+  coords_at_dist(e, c, sx, lat1, lon1);
+  const double te0 = terrain_elev_or_zero(fg->tv, lat0, lon0), te1 = terrain_elev_or_zero(fg->tv, lat1, lon1);
+  const double diff1 = re0 - te0, diff2 = sh - te1;
+  StepHits hits;
+  hits.n = 0;
+  hits.finish = false;
+  if (diff1 * diff2 < 0.0) { // utils.rs:222
+    step_push(hits, diff1 / (diff1 - diff2), -1, nullptr);
+    if (fg->p.terrain_alpha == 1.0) hits.finish = true;
+  }
+  // the objects this step tests, ascending: those close to either sample (utils.rs:241-250) whose height band the segment enters
+  const Vec3 pos1 = as_cartesian(e, lat0, lon0, re0), pos2 = as_cartesian(e, lat1, lon1, sh);
+  const LatLonTrig t0 = latlon_trig(e, lat0, lon0), t1 = latlon_trig(e, lat1, lon1);
+  const double x_prev = sx - fg->p.simulation_step * 1.000001;
+  for (int q = 0; q < n_e; q++) {
+    if (w_hi[q] < x_prev || w_lo[q] > sx) continue; // the wavefront's interval of this object does not reach the step
+    const int j = w_obj[q];
+    const ObjectDev& o = fg->objects[j];
+    if (object_out_of_band(o, re0, sh)) continue;
+    if (!(object_is_close(e, o, t0) || object_is_close(e, o, t1))) continue;
+    step_object_impl(hits, fg->objects, fg->textures, j, pos1, pos2);
+  }
+  // emission: the counting pass of the general tracer (k_rect_trace<false>)
+  const unsigned count = io->count;
+  const uint32_t p = io->pixel;
+  if (hits.n > STEP_CANDIDATES) atomicAdd(&sk->counters[6], 1ull); // the fill pass will need Workspace::step_prop
+  if (hits.n && count + (unsigned)hits.n <= (unsigned)RECT_SLOTS) {
+    uint64_t k = (uint64_t)p * RECT_SLOTS + count;
+    const uint64_t k0 = k;
+    step_emit(hits, sk->slot_packed, sk->slot_step, sk->slot_pixel, k, p, io->step_index, lat0, lon0, re0, d0, pl0, lat1, lon1, sh, sx, path_length);
+    for (uint64_t q = k0; q < k; q++) { // terrain points: what k_rect_finalize_list needs
+      sk->slots.re0[q] = re0;
+      sk->slots.pl0[q] = pl0;
+      sk->slots.re1[q] = sh;
+      sk->slots.pl1[q] = path_length;
+    }
+  } else if (hits.n && hits.n <= STEP_CANDIDATES && sk->ovf.cap) { // beyond the slots: the step's points into the overflow arena
+    const unsigned long long base = atomicAdd(&sk->counters[13], (unsigned long long)hits.n);
+    if (base + (unsigned long long)hits.n <= sk->ovf.cap) {
+      uint64_t kk = base;
+      step_emit(hits, sk->ovf_packed, sk->ovf.step, sk->ovf.pixel, kk, p, io->step_index, lat0, lon0, re0, d0, pl0, lat1, lon1, sh, sx, path_length);
+      for (uint64_t q = base; q < kk; q++) {
+        sk->ovf.ordinal[q] = count + (unsigned)(q - base);
+        sk->ovf.re0[q] = re0;
+        sk->ovf.pl0[q] = pl0;
+        sk->ovf.re1[q] = sh;
+        sk->ovf.pl1[q] = path_length;
+      }
+    }
+  }
+  atomicAdd(&sk->counters[14], 1ull); // statistics (atmrt_last_stats().object_steps)
+  io->count = count + (unsigned)hits.n;
+  io->finish = hits.finish ? 1 : 0;
+  io->diff1 = diff2;
+}
+
 #ifdef ATMRT_TIMELINE
 // Experiment hook (tools/measure_march_timeline.py; never defined in the product build): start / end time and steps of every
 // wavefront of the last k_rect_march launch, read back through atmrt_debug_timeline.
@@ -116,7 +206,8 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
                                                     const uint64_t* __restrict__ hit_offset, RectRec rec,
                                                     uint32_t* __restrict__ list_step, uint32_t* __restrict__ list_pixel,
                                                     unsigned long long* __restrict__ counters,
-                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list, OverflowArena ovf) {
+                                                    const uint32_t* __restrict__ pixel_list, uint32_t n_list, OverflowArena ovf,
+                                                    const Frame* __restrict__ frame_dev, const ObjectStepSinks* __restrict__ sinks_dev) {
 #ifdef ATMRT_TIMELINE
   const unsigned long long tl_t0 = wall_clock64();
 #endif
@@ -153,6 +244,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
     double x_wake = dm_inf();
     __shared__ double w_lo[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1], w_hi[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1],
         w_vlo[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1], w_vhi[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1];
+    __shared__ int w_obj[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1];
     const int wv = threadIdx.x >> 6;
     if (MODE == 3) {
       if (!candidates_supported<CALC>(e)) {
@@ -180,6 +272,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
                 w_hi[wv][w_n] = hi;
                 w_vlo[wv][w_n] = f.objects[j].vlo;
                 w_vhi[wv][w_n] = f.objects[j].vhi;
+                w_obj[wv][w_n] = j;
               }
             }
             w_n++;
@@ -224,6 +317,7 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
           const double x_prev = sx - step * 1.000001; // a little before the older sample (its x is sx - step up to rounding)
           double next = dm_inf();
           const int n_e = w_n < WAVE_CAND ? w_n : WAVE_CAND;
+          bool object_step = false;
           for (int q = 0; q < n_e; q++) {
             const double lo = w_lo[wv][q], hi = w_hi[wv][q];
             if (hi < x_prev) continue;               // behind the step
@@ -233,10 +327,34 @@ __global__ __launch_bounds__(DRAIN ? ATMRT_MARCH_BLOCK_SMALL : 256, DRAIN ? ATMR
             }
             next = sx;                               // being crossed: look again at the next step
             const double vlo = w_vlo[wv][q], vhi = w_vhi[wv][q];
-            if (!((re0 < vlo && sh < vlo) || (re0 > vhi && sh > vhi))) object_ray = true; // object_out_of_band is false
+            if (!((re0 < vlo && sh < vlo) || (re0 > vhi && sh > vhi))) object_step = true; // object_out_of_band is false
           }
           x_wake = next;
-          if (object_ray) break;
+          // A launch of many resident sets (the whole frame: DRAIN false) abandons the ray here and leaves it to the general tracer,
+          // whose own launch is then large enough to fill the chip (config 5: 38 ms of VALU-saturated work for 11 % of the rays —
+          // there is nothing to hide, and the out-of-line steps would only add their call overhead: 308 against 328 ms per frame).
+          // A small launch (a column tile of a multi-GPU frame: DRAIN true) keeps the ray and does the step out of line: the
+          // tracer's launch for a tile would be under two wavefronts per SIMD, 12 ms whatever the tile's size (8 tiles: 54 -> 43 ms).
+          if (object_step && !DRAIN) {
+            object_ray = true;
+            break;
+          }
+          if (object_step) { // this lane's step in full, out of line (object_step_impl above); the others wait
+            ObjectStepIO io;
+            io.c = c;
+            io.d0 = f.xs[i - 1]; // the stepper's x of the older sample: 0 + step + ... (the same additions as xs)
+            io.sx = sx, io.re0 = re0, io.sh = sh, io.pl0 = pl0, io.path_length = path_length;
+            io.pixel = (uint32_t)p, io.step_index = i - 1, io.count = count;
+            object_step_impl<CALC>(frame_dev, sinks_dev, &io, w_lo[wv], w_hi[wv], w_obj[wv], n_e);
+            count = io.count;
+            lookups += 2;
+            steps++;
+            if (io.finish) break;
+            diff0 = io.diff1;
+            re0 = sh;
+            pl0 = path_length;
+            continue;
+          }
         }
         // A sample above every post of the mosaic is above the terrain, whatever its geodesic point: ray - terrain is positive and
         // only its SIGN enters the test below (the epilogue rebuilds the bracketing samples in full), so the geodesic point and
@@ -973,7 +1091,8 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
   if (f.opaque) {
     if (!launch_rect_march_sliced<0, CUBIC>(f, ws, out, SliceSinks{ws.hit_step, rec, nullptr, OverflowArena{}}, stream)) {
       ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{});
+                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{}, (const Frame*)nullptr,
+                         (const ObjectStepSinks*)nullptr);
     }
     (void)hipEventRecord(ev_marched, stream);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize<CALC>), dim3(cdiv(n, 256)), dim3(256), 0, stream,
@@ -983,7 +1102,8 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
     const OverflowArena ovf = carve_overflow(ws.overflow_arena, ws.overflow_cap);
     if (!launch_rect_march_sliced<1, CUBIC>(f, ws, out, SliceSinks{nullptr, slots, ws.slot_step, ovf}, stream)) {
       ATMRT_LAUNCH_MARCH(1, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, (uint32_t*)nullptr,
-                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, ovf);
+                         (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, ovf, (const Frame*)nullptr,
+                         (const ObjectStepSinks*)nullptr);
     }
     (void)hipEventRecord(ev_marched, stream);
   }
@@ -1056,7 +1176,8 @@ void launch_multi_fill_t(const Frame& f, Workspace& ws, uint64_t n_hits, const D
                          ws.list_pixel, rec);
   } else if (ws.n_overflow) {
     ATMRT_LAUNCH_MARCH(2, ws.n_overflow, stream, f, dense, ws.hit_step, ws.hit_offset, rec, ws.list_step, ws.list_pixel,
-                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow, OverflowArena{});
+                       (unsigned long long*)ws.counters, (const uint32_t*)ws.overflow, (uint32_t)ws.n_overflow, OverflowArena{},
+                       (const Frame*)nullptr, (const ObjectStepSinks*)nullptr);
   }
   if (n_hits) {
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_finalize_list<CALC>), dim3(cdiv(n_hits, 256)), dim3(256), 0,
@@ -1086,8 +1207,22 @@ template <bool CUBIC>
 void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes& out, hipStream_t stream) {
   size_t n = (size_t)f.wl * f.h;
   RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
+  // the frame and the tracer's arenas where the out-of-line object step can address them (object_step_impl): copies in HBM
+  ObjectStepSinks sinks{};
+  sinks.slot_packed = ws.slot_packed;
+  sinks.slots = slots;
+  sinks.slot_step = ws.slot_step;
+  sinks.slot_pixel = ws.slot_pixel;
+  sinks.ovf = trace_overflow_arena(ws);
+  sinks.ovf_packed = ws.overflow_packed;
+  sinks.counters = (unsigned long long*)ws.counters;
+  const Frame* frame_dev = reinterpret_cast<const Frame*>(ws.step_ctx);
+  const ObjectStepSinks* sinks_dev = reinterpret_cast<const ObjectStepSinks*>(ws.step_ctx + (sizeof(Frame) + 255) / 256 * 256);
+  (void)hipMemcpyAsync(ws.step_ctx, &f, sizeof f, hipMemcpyHostToDevice, stream);
+  (void)hipMemcpyAsync(const_cast<ObjectStepSinks*>(sinks_dev), &sinks, sizeof sinks, hipMemcpyHostToDevice, stream);
+  (void)hipStreamSynchronize(stream); // both sources are on this stack frame
   ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
-                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws));
+                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws), frame_dev, sinks_dev);
   hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
                      (unsigned long long*)ws.counters);
 }

@@ -1399,6 +1399,7 @@ int atmrt::multi_last_stats(atmrt_ctx* parent, atmrt_frame_stats_t* out) {
     t.big_blend_pixels += a.big_blend_pixels;
     t.terrain_lookups += a.terrain_lookups;
     t.object_rays += a.object_rays;
+    t.object_steps += a.object_steps;
   }
   *out = t;
   return ATMRT_OK;

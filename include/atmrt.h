@@ -287,8 +287,11 @@ typedef struct atmrt_frame_stats {
                                  above the highest post of the mosaic (+ 1 m) is above the terrain for certain, so its geodesic
                                  point and lookup are not evaluated — every ODE step, sign test and result stays the same;
                                  ray_steps keeps counting every step */
-  uint64_t object_rays;       /* Rectilinear, scenes with objects: rays that came within a candidate object's distance interval
-                                 and height band, traced by the general tracer; the others keep the lean march's result */
+  uint64_t object_rays;       /* Rectilinear, scenes with objects: rays left to the general tracer — since round 4 only those of
+                                 wavefronts with more candidate objects than the wavefront's list holds (96), or of an earth model
+                                 without the geometric pre-filter; every other ray stays with the lean march */
+  uint64_t object_steps;      /* Rectilinear, scenes with objects: ray-steps the lean march handed to its out-of-line object step
+                                 (the step lies inside a candidate object's distance interval and enters its height band) */
 } atmrt_frame_stats_t;
 int atmrt_last_stats(atmrt_ctx* ctx, atmrt_frame_stats_t* out);
 /* Fault injection for tests of the error paths: the next atmrt_generate / atmrt_generate_device on ctx runs its kernels and then

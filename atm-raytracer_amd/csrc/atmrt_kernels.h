@@ -135,6 +135,10 @@ static inline int march_variant_override() {
   }();
   return v;
 }
+constexpr int WAVE_CAND = 96; // entries of a wavefront's candidate list (scenes with objects); more: every ray of the wavefront is left to the tracer
+// a group's list between two slices: lo, hi, vlo, vhi (f64) and the object index (i32) of every entry, the number of entries and
+// the next wake distance
+constexpr size_t SLICE_GROUP_LIST_BYTES = (size_t)WAVE_CAND * (4 * sizeof(double) + sizeof(int32_t)) + 2 * sizeof(double);
 struct SliceLayout {
   uint32_t n_groups;     // groups of 64 consecutive pixels
   size_t n_pad;          // pixels rounded up to whole groups
@@ -146,7 +150,7 @@ struct SliceLayout {
 static inline bool march_slice_layout(const Frame& f, SliceLayout& L) {
   const size_t n = (size_t)f.wl * f.h;
   const int ov = march_variant_override();
-  if (f.p.generator != ATMRT_GEN_RECTILINEAR || f.n_objects != 0 || n == 0 || f.n_t + 2 <= MARCH_SLICE_STEPS) return false;
+  if (f.p.generator != ATMRT_GEN_RECTILINEAR || n == 0 || f.n_t + 2 <= MARCH_SLICE_STEPS) return false;
   if (ov ? ov != 3 : (n + 255) / 256 > MARCH_SMALL_MAX_BLOCKS) return false;
   L.n_groups = (uint32_t)((n + 63) / 64);
   L.n_pad = (size_t)L.n_groups * 64;
@@ -154,6 +158,8 @@ static inline bool march_slice_layout(const Frame& f, SliceLayout& L) {
   L.cap = (size_t)L.n_groups * L.slices_after;
   if (L.cap > 0x7fffffffull) return false; // (a frame of > 2^31 slices is marched whole)
   L.bytes = L.n_pad * (7 * sizeof(double) + 3 * sizeof(int32_t) + sizeof(DirCalc)) + 64 + L.cap * sizeof(uint32_t);
+  // scenes with objects: every group's candidate list (what a wavefront of k_rect_march<3> keeps in LDS) travels with its state
+  if (f.n_objects) L.bytes += 256 + (size_t)L.n_groups * SLICE_GROUP_LIST_BYTES;
   return true;
 }
 

@@ -50,7 +50,6 @@ namespace atmrt {
 // is a superset of every ray's own candidates (same candidate_interval as ray_candidates), the band test is the tracer's own
 // (object_out_of_band), so a ray that is never flagged has provably no step with an object: its terrain-only result is final.
 constexpr uint32_t OBJECT_RAY = 0xffffffffu; // hit_count of a ray left to k_rect_trace
-constexpr int WAVE_CAND = 96;                // entries of a wavefront's list; more: every ray of the wavefront is left to the tracer
 
 // Wave priority against the drain at the end of a launch.  The SIMD issues oldest-wave-first, so the four wavefronts that share a
 // SIMD in the LAST resident set do not finish together: the favoured one runs at its dependency-chain speed, and the last one
@@ -479,6 +478,33 @@ struct SliceState {
   uint32_t* queue;                           // [cap], 0xffffffff = not written yet
   unsigned long long* ctl;                   // [4]
   uint32_t cap;
+  char* glist;                               // MODE 3: [n_groups] candidate lists of SLICE_GROUP_LIST_BYTES each, or null
+};
+// a group's candidate list in HBM (MODE 3): the arrays of one record
+struct GroupList {
+  double *lo, *hi, *vlo, *vhi;
+  int32_t* obj;
+  double* n_and_wake; // [0] number of entries (as a double), [1] x_wake
+};
+static __device__ __forceinline__ GroupList group_list(char* base, uint32_t group) {
+  char* q = base + (size_t)group * SLICE_GROUP_LIST_BYTES;
+  GroupList g;
+  g.n_and_wake = (double*)q;
+  g.lo = g.n_and_wake + 2;
+  g.hi = g.lo + WAVE_CAND;
+  g.vlo = g.hi + WAVE_CAND;
+  g.vhi = g.vlo + WAVE_CAND;
+  g.obj = (int32_t*)(g.vhi + WAVE_CAND);
+  return g;
+}
+// what a slice of a scene with objects needs besides the ray: the wavefront's list (LDS), its wake distance, and where the
+// out-of-line object step finds the frame and the tracer's arenas
+struct SliceObjects {
+  const double *w_lo, *w_hi, *w_vlo, *w_vhi;
+  const int* w_obj;
+  int n_e;
+  const Frame* frame_dev;
+  const ObjectStepSinks* sinks_dev;
 };
 constexpr uint32_t SLICE_EMPTY = 0xffffffffu, SLICE_EXIT = 0xfffffffeu;
 #ifndef ATMRT_SLICE_WAVES
@@ -497,10 +523,11 @@ static __device__ __forceinline__ int timeline_wave_max(int v) {
 
 // What a slice leaves behind besides the state: MODE 0 the first crossing, MODE 1 the slots of the counting march (k_rect_march<1>)
 struct SliceSinks {
-  int32_t* hit_step;   // MODE 0
-  RectRec rec;         // MODE 0: [plane]; MODE 1: slot-major [RECT_SLOTS][plane]
-  uint32_t* slot_step; // MODE 1
-  OverflowArena ovf;   // MODE 1: crossings beyond the slots
+  int32_t* hit_step;   // MODE 0; MODE 3: 1 = the ray is left to the general tracer
+  RectRec rec;         // MODE 0: [plane]; MODE 1: slot-major [RECT_SLOTS][plane]; MODE 3: pixel-major [plane][RECT_SLOTS] (the tracer's arena)
+  uint32_t* slot_step; // MODE 1, MODE 3
+  OverflowArena ovf;   // MODE 1, MODE 3: crossings beyond the slots
+  uint32_t* slot_tag;  // MODE 3: the slot arena's colour tags (the march writes TERRAIN)
 };
 
 // one slice of the march of a ray whose state is in registers; returns true when the ray is still marching after step i0 + slice
@@ -508,7 +535,8 @@ template <int MODE, int CALC, bool CUBIC>
 static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& e, const DirCalc& c, Stepper& s, double& sh,
                                                    double& path_length, double& diff0, double& re0, double& pl0, int i0, int slice,
                                                    int& first, unsigned& count, const SliceSinks& sinks, unsigned long long* counters, size_t p,
-                                                   size_t plane, unsigned long long& steps, unsigned long long& lookups) {
+                                                   size_t plane, unsigned long long& steps, unsigned long long& lookups,
+                                                   const SliceObjects& so, double& x_wake) {
   const bool sph = e.spherical != 0;
   const double radius = e.shape_radius;
   const bool straight = f.p.straight_rays != 0;
@@ -524,6 +552,40 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
     sx = nx.x;
     sh = nx.h;
     if (sx > max_dist || sh < -1000.0 || !(sx <= max_dist)) return false; // rectilinear.rs:178 (+ NaN guard)
+    if (MODE == 3 && sx >= x_wake) { // wave-uniform, as in k_rect_march<3>: this step against the group's candidate list
+      const double x_prev = sx - step * 1.000001;
+      double next = dm_inf();
+      bool object_step = false;
+      for (int q = 0; q < so.n_e; q++) {
+        const double lo = so.w_lo[q], hi = so.w_hi[q];
+        if (hi < x_prev) continue;
+        if (lo > sx) {
+          next = lo < next ? lo : next;
+          continue;
+        }
+        next = sx;
+        const double vlo = so.w_vlo[q], vhi = so.w_vhi[q];
+        if (!((re0 < vlo && sh < vlo) || (re0 > vhi && sh > vhi))) object_step = true;
+      }
+      x_wake = next;
+      if (object_step) { // this lane's step in full, out of line (object_step_impl)
+        ObjectStepIO io;
+        io.c = c;
+        io.d0 = f.xs[i - 1];
+        io.sx = sx, io.re0 = re0, io.sh = sh, io.pl0 = pl0, io.path_length = path_length;
+        io.pixel = (uint32_t)p, io.step_index = i - 1, io.count = count;
+        object_step_impl<CALC>(so.frame_dev, so.sinks_dev, &io, so.w_lo, so.w_hi, so.w_obj, so.n_e);
+        count = io.count;
+        lookups += 2;
+        steps++;
+        if (io.finish) return false;
+        diff0 = io.diff1;
+        re0 = sh;
+        pl0 = path_length;
+        if (i == i_end) return true;
+        continue;
+      }
+    }
     double diff1 = 1.0; // above every post of the mosaic: see k_rect_march
     if (!(sh > skip_above)) {
       coords_at_dist(e, c, sx, lat, lon);
@@ -536,9 +598,10 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
         first = i - 1;
         return false;
       }
-      if (count < (unsigned)RECT_SLOTS) { // as k_rect_march<1>
-        const size_t q = (size_t)count * plane + p;
+      if (count < (unsigned)RECT_SLOTS) { // as k_rect_march<1> / <3>
+        const size_t q = MODE == 3 ? p * RECT_SLOTS + count : (size_t)count * plane + p;
         sinks.slot_step[q] = (uint32_t)(i - 1);
+        if (MODE == 3) sinks.slot_tag[q] = ATMRT_COLOR_TERRAIN;
         sinks.rec.re0[q] = re0;
         sinks.rec.pl0[q] = pl0;
         sinks.rec.re1[q] = sh;
@@ -547,6 +610,7 @@ static __device__ __forceinline__ bool march_slice(const Frame& f, const Earth& 
         overflow_append(sinks.ovf, counters, (uint32_t)p, count, (uint32_t)(i - 1), re0, pl0, sh, path_length);
       }
       count++;
+      if (MODE == 3 && f.p.terrain_alpha == 1.0) return false; // opaque terrain ends the ray (utils.rs:237-239)
     }
     diff0 = diff1;
     re0 = sh;
@@ -570,6 +634,7 @@ static __device__ __forceinline__ void slice_finish(const DensePlanes& out, cons
     sinks.hit_step[p] = first;
   } else {
     out.hit_count[p] = count;
+    if (MODE == 3) sinks.hit_step[p] = 0; // the ray stayed with the march: its overflow records count (k_rect_scatter_trace_overflow)
     if (count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
   }
 }
@@ -592,7 +657,8 @@ static __device__ __forceinline__ void slice_requeue(const SliceState& st, uint3
 template <int MODE, int CALC, bool CUBIC>
 __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Frame f, DensePlanes out, SliceSinks sinks,
                                                                              unsigned long long* __restrict__ counters, SliceState st,
-                                                                             uint32_t n_groups, int slice) {
+                                                                             uint32_t n_groups, int slice, const Frame* __restrict__ frame_dev,
+                                                                             const ObjectStepSinks* __restrict__ sinks_dev) {
 #ifdef ATMRT_TIMELINE
   const unsigned long long tl_t0 = wall_clock64();
 #endif
@@ -616,15 +682,83 @@ __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Fra
     int first = -1;
     unsigned count = 0;
     double sh = alt, path_length = 0.0, re0 = alt, pl0 = 0.0, diff0 = 0.0;
-    if (!(0.0 > f.p.frame.max_distance || alt < -1000.0)) { // the reference would panic on an empty stream
+    // MODE 3: the wavefront's candidate list, built as k_rect_march<3> builds it (LDS) and kept in HBM for the group's later slices
+    __shared__ double w_lo[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1], w_hi[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1],
+        w_vlo[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1], w_vhi[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1];
+    __shared__ int w_obj[MODE == 3 ? 4 : 1][MODE == 3 ? WAVE_CAND : 1];
+    const int wv = threadIdx.x >> 6;
+    int w_n = 0;
+    double x_wake = dm_inf();
+    bool object_ray = false; // MODE 3: the list overflowed (or the earth model has no pre-filter): the wavefront's rays go to the tracer
+    if (MODE == 3) {
+      if (!candidates_supported<CALC>(e)) {
+        object_ray = true;
+      } else {
+        const Vec3 nrm = track_normal<CALC>(c);
+        for (int j = 0; j < f.n_objects; j++) { // wave-uniform loop; the object's fields are scalar loads
+          double lo = dm_inf(), hi = -dm_inf();
+          double l, h;
+          if (candidate_interval<CALC>(e, c, nrm, f.objects[j], true, l, h)) lo = l, hi = h;
+          unsigned long long holders = __ballot(lo <= hi);
+          if (holders) {
+            double wlo = dm_inf(), whi = -dm_inf();
+            for (; holders; holders &= holders - 1) {
+              const int src = __builtin_ctzll(holders);
+              const double l2 = __shfl(lo, src, 64), h2 = __shfl(hi, src, 64);
+              wlo = l2 < wlo ? l2 : wlo;
+              whi = h2 > whi ? h2 : whi;
+            }
+            if (w_n < WAVE_CAND && (threadIdx.x & 63) == 0) {
+              w_lo[wv][w_n] = wlo;
+              w_hi[wv][w_n] = whi;
+              w_vlo[wv][w_n] = f.objects[j].vlo;
+              w_vhi[wv][w_n] = f.objects[j].vhi;
+              w_obj[wv][w_n] = j;
+            }
+            w_n++;
+          }
+        }
+        if (w_n > WAVE_CAND) object_ray = true;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int q = 0; q < w_n && q < WAVE_CAND; q++)
+          if (w_hi[wv][q] >= 0.0) x_wake = w_lo[wv][q] < x_wake ? w_lo[wv][q] : x_wake;
+      }
+    }
+    const int n_e = w_n < WAVE_CAND ? w_n : WAVE_CAND;
+    const SliceObjects so{w_lo[wv], w_hi[wv], w_vlo[wv], w_vhi[wv], w_obj[wv], n_e, frame_dev, sinks_dev};
+    if (!(0.0 > f.p.frame.max_distance || alt < -1000.0) && !object_ray) { // the reference would panic on an empty stream
       double lat, lon;
       coords_at_dist(e, c, 0.0, lat, lon);
       diff0 = alt - terrain_elev_or_zero(f.tv, lat, lon);
       lookups++;
       alive = march_slice<MODE, CALC, CUBIC>(f, e, c, s, sh, path_length, diff0, re0, pl0, 0, slice, first, count, sinks, counters, p, plane,
-                                             steps, lookups);
+                                             steps, lookups, so, x_wake);
     }
-    if (alive) {
+    if (MODE == 3 && st.glist && __any(alive)) { // the group marches on: its list and wake distance for the slices to come
+      const GroupList gl = group_list(st.glist, (uint32_t)(p >> 6));
+      const int lane = threadIdx.x & 63;
+      for (int q = lane; q < n_e; q += 64) {
+        gl.lo[q] = w_lo[wv][q];
+        gl.hi[q] = w_hi[wv][q];
+        gl.vlo[q] = w_vlo[wv][q];
+        gl.vhi[q] = w_vhi[wv][q];
+        gl.obj[q] = w_obj[wv][q];
+      }
+      const unsigned long long still = __ballot(alive); // (a lane that ended inside the slice holds an older wake distance)
+      if (lane == __builtin_ctzll(still)) {
+        gl.n_and_wake[0] = (double)n_e;
+        gl.n_and_wake[1] = x_wake;
+      }
+    }
+    if (MODE == 3 && object_ray) { // left to the general tracer (k_collect_object_rays, k_rect_trace)
+      st.step[p] = -1;
+      out.hit_count[p] = OBJECT_RAY;
+      sinks.hit_step[p] = 1;
+      steps = 0;
+      lookups = 0;
+    } else if (alive) {
       st.x[p] = s.x;
       st.a[p] = s.a;
       st.b[p] = s.b;
@@ -634,7 +768,7 @@ __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Fra
       st.pl[p] = path_length;
       st.diff0[p] = diff0;
       st.step[p] = slice;
-      if (MODE == 1) st.count[p] = count;
+      if (MODE == 1 || MODE == 3) st.count[p] = count;
       st.calc[p] = c;
     } else {
       st.step[p] = -1;
@@ -665,7 +799,8 @@ __global__ __launch_bounds__(256, ATMRT_SLICE_WAVES) void k_rect_march_first(Fra
 template <int MODE, int CALC, bool CUBIC>
 __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame f, DensePlanes out, SliceSinks sinks,
                                                                            unsigned long long* __restrict__ counters, SliceState st,
-                                                                           uint32_t n_groups, int slice) {
+                                                                           uint32_t n_groups, int slice, const Frame* __restrict__ frame_dev,
+                                                                           const ObjectStepSinks* __restrict__ sinks_dev) {
   const size_t plane = (size_t)f.wl * f.h;
   const int lane = threadIdx.x;
   uint32_t item = 0;
@@ -703,6 +838,27 @@ __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame
   const size_t p = (size_t)item * 64 + lane;
   bool alive = false;
   const int32_t i0 = p < plane ? st.step[p] : -1;
+  // MODE 3: the group's candidate list back into LDS (what its first slice built)
+  __shared__ double w_lo[MODE == 3 ? WAVE_CAND : 1], w_hi[MODE == 3 ? WAVE_CAND : 1], w_vlo[MODE == 3 ? WAVE_CAND : 1], w_vhi[MODE == 3 ? WAVE_CAND : 1];
+  __shared__ int w_obj[MODE == 3 ? WAVE_CAND : 1];
+  int n_e = 0;
+  double x_wake = dm_inf();
+  if (MODE == 3) {
+    const GroupList gl = group_list(st.glist, item);
+    n_e = (int)gl.n_and_wake[0];
+    x_wake = gl.n_and_wake[1];
+    for (int q = lane; q < n_e; q += 64) {
+      w_lo[q] = gl.lo[q];
+      w_hi[q] = gl.hi[q];
+      w_vlo[q] = gl.vlo[q];
+      w_vhi[q] = gl.vhi[q];
+      w_obj[q] = gl.obj[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const SliceObjects so{w_lo, w_hi, w_vlo, w_vhi, w_obj, n_e, frame_dev, sinks_dev};
   if (i0 >= 0) {
     const Earth e = earth_for<CALC>(f);
     Stepper s;
@@ -716,9 +872,9 @@ __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame
     const DirCalc c = st.calc[p];
     double re0 = sh, pl0 = path_length;
     int first = -1;
-    unsigned count = MODE == 1 ? st.count[p] : 0u;
+    unsigned count = MODE == 1 || MODE == 3 ? st.count[p] : 0u;
     alive = march_slice<MODE, CALC, CUBIC>(f, e, c, s, sh, path_length, diff0, re0, pl0, i0, slice, first, count, sinks, counters, p, plane,
-                                           steps, lookups);
+                                           steps, lookups, so, x_wake);
     if (alive) {
       st.x[p] = s.x;
       st.a[p] = s.a;
@@ -728,11 +884,15 @@ __global__ __launch_bounds__(64, ATMRT_SLICE_WAVES) void k_rect_march_cont(Frame
       st.pl[p] = path_length;
       st.diff0[p] = diff0;
       st.step[p] = i0 + slice;
-      if (MODE == 1) st.count[p] = count;
+      if (MODE == 1 || MODE == 3) st.count[p] = count;
     } else {
       st.step[p] = -1;
       slice_finish<MODE>(out, sinks, counters, p, first, count, re0, pl0, sh, path_length);
     }
+  }
+  if (MODE == 3) { // the group's next wake distance, from a lane that is still marching (the value is the same in all of them)
+    const unsigned long long still = __ballot(alive); // (a lane that ended inside the slice holds an older one)
+    if (still && lane == __builtin_ctzll(still)) group_list(st.glist, item).n_and_wake[1] = x_wake;
   }
   slice_requeue(st, item, alive);
 #ifdef ATMRT_TIMELINE
@@ -1275,7 +1435,8 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
 // marching (it bounds the entries the later slices can write: the grid of the second kernel), then one wavefront per entry.
 // false: the frame is not sliced (march_slice_layout) and the caller launches k_rect_march.
 template <int MODE, bool CUBIC>
-static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DensePlanes& out, const SliceSinks& sinks, hipStream_t stream) {
+static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DensePlanes& out, const SliceSinks& sinks, hipStream_t stream,
+                                     const Frame* frame_dev = nullptr, const ObjectStepSinks* sinks_dev = nullptr) {
   SliceLayout L;
   if (!ws.slice_state || !march_slice_layout(f, L)) return false;
   const size_t n = (size_t)f.wl * f.h;
@@ -1296,9 +1457,10 @@ static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DenseP
   st.ctl = (unsigned long long*)q; q += 64;
   st.queue = (uint32_t*)q;
   st.cap = (uint32_t)L.cap;
+  st.glist = f.n_objects ? (char*)(((uintptr_t)(st.queue + L.cap) + 255) / 256 * 256) : nullptr;
   (void)hipMemsetAsync(st.ctl, 0, 64, stream);
   ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_first<MODE, CALC, CUBIC>), dim3(cdiv(n, 256)), dim3(256), 0, stream, f,
-                                                        out, sinks, (unsigned long long*)ws.counters, st, L.n_groups, slice));
+                                                        out, sinks, (unsigned long long*)ws.counters, st, L.n_groups, slice, frame_dev, sinks_dev));
   unsigned long long ctl_host[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(ctl_host, st.ctl, sizeof ctl_host, hipMemcpyDeviceToHost, stream) != hipSuccess ||
       hipStreamSynchronize(stream) != hipSuccess)
@@ -1308,7 +1470,7 @@ static bool launch_rect_march_sliced(const Frame& f, Workspace& ws, const DenseP
   if (entries) {
     (void)hipMemsetAsync(st.queue + ctl_host[1], 0xff, (entries - (size_t)ctl_host[1]) * sizeof(uint32_t), stream);
     ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march_cont<MODE, CALC, CUBIC>), dim3((unsigned)entries), dim3(64), 0, stream,
-                                                          f, out, sinks, (unsigned long long*)ws.counters, st, L.n_groups, slice));
+                                                          f, out, sinks, (unsigned long long*)ws.counters, st, L.n_groups, slice, frame_dev, sinks_dev));
   }
   hipLaunchKernelGGL(k_slice_check, dim3(1), dim3(1), 0, stream, (const unsigned long long*)st.ctl, L.n_groups,
                      (unsigned long long*)ws.counters);
@@ -1320,7 +1482,7 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
   size_t n = (size_t)f.wl * f.h;
   RectRec rec = carve_rec(ws.rect_rec, n);
   if (f.opaque) {
-    if (!launch_rect_march_sliced<0, CUBIC>(f, ws, out, SliceSinks{ws.hit_step, rec, nullptr, OverflowArena{}}, stream)) {
+    if (!launch_rect_march_sliced<0, CUBIC>(f, ws, out, SliceSinks{ws.hit_step, rec, nullptr, OverflowArena{}, nullptr}, stream)) {
       ATMRT_LAUNCH_MARCH(0, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, rec, (uint32_t*)nullptr, (uint32_t*)nullptr,
                          (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, OverflowArena{}, (const Frame*)nullptr,
                          (const ObjectStepSinks*)nullptr);
@@ -1331,7 +1493,7 @@ void launch_rect_march_t(const Frame& f, Workspace& ws, const DensePlanes& out, 
   } else {
     RectRec slots = carve_rec(ws.slot_rec, n * RECT_SLOTS);
     const OverflowArena ovf = carve_overflow(ws.overflow_arena, ws.overflow_cap);
-    if (!launch_rect_march_sliced<1, CUBIC>(f, ws, out, SliceSinks{nullptr, slots, ws.slot_step, ovf}, stream)) {
+    if (!launch_rect_march_sliced<1, CUBIC>(f, ws, out, SliceSinks{nullptr, slots, ws.slot_step, ovf, nullptr}, stream)) {
       ATMRT_LAUNCH_MARCH(1, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, (uint32_t*)nullptr,
                          (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, ovf, (const Frame*)nullptr,
                          (const ObjectStepSinks*)nullptr);
@@ -1452,8 +1614,12 @@ void launch_rect_trace_count_t(const Frame& f, Workspace& ws, const DensePlanes&
   (void)hipMemcpyAsync(ws.step_ctx, &f, sizeof f, hipMemcpyHostToDevice, stream);
   (void)hipMemcpyAsync(const_cast<ObjectStepSinks*>(sinks_dev), &sinks, sizeof sinks, hipMemcpyHostToDevice, stream);
   (void)hipStreamSynchronize(stream); // both sources are on this stack frame
-  ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
-                     (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws), frame_dev, sinks_dev);
+  // a small launch (a column tile): the time-sliced march, its groups carrying their candidate lists; else the whole grid at once
+  if (!launch_rect_march_sliced<3, CUBIC>(f, ws, out, SliceSinks{ws.hit_step, slots, ws.slot_step, trace_overflow_arena(ws), ws.slot_packed.color_tag},
+                                          stream, frame_dev, sinks_dev)) {
+    ATMRT_LAUNCH_MARCH(3, n, stream, f, out, ws.hit_step, (const uint64_t*)nullptr, slots, ws.slot_step, ws.slot_packed.color_tag,
+                       (unsigned long long*)ws.counters, (const uint32_t*)nullptr, 0u, trace_overflow_arena(ws), frame_dev, sinks_dev);
+  }
   hipLaunchKernelGGL(k_collect_object_rays, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (const uint32_t*)out.hit_count, ws.object_rays,
                      (unsigned long long*)ws.counters);
 }

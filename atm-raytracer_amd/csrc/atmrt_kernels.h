@@ -146,11 +146,16 @@ struct SliceLayout {
   size_t cap;            // FIFO entries: n_groups x slices_after
   size_t bytes;          // of Workspace::slice_state
 };
-// false: this frame's march is not sliced (scene objects, rays one slice long, too big a launch, or forced otherwise)
+// false: this frame's march is not sliced (scene objects unless forced, rays one slice long, too big a launch, or forced otherwise)
 static inline bool march_slice_layout(const Frame& f, SliceLayout& L) {
   const size_t n = (size_t)f.wl * f.h;
   const int ov = march_variant_override();
   if (f.p.generator != ATMRT_GEN_RECTILINEAR || n == 0 || f.n_t + 2 <= MARCH_SLICE_STEPS) return false;
+  // Scenes with objects CAN be sliced (round 4: a group's candidate list travels with its state, the object steps are done out of
+  // line inside the slices; bit-identical, tests/test_gpu_march_variants.py) but are not by default: config 5's tiles at 8 GPUs
+  // take 8 x 43.8 ms sliced against 8 x 42.3 ms through the small-launch variant of k_rect_march<3> (the slices that contain object
+  // steps run long and put their groups out of step) — ATMRT_MARCH_VARIANT=sliced forces it.
+  if (f.n_objects != 0 && ov != 3) return false;
   if (ov ? ov != 3 : (n + 255) / 256 > MARCH_SMALL_MAX_BLOCKS) return false;
   L.n_groups = (uint32_t)((n + 63) / 64);
   L.n_pad = (size_t)L.n_groups * 64;

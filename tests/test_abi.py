@@ -89,10 +89,7 @@ def test_march_plan_of_frames_and_tiles(lib):
     assert cap == groups * after
     assert nbytes == 512 * 2048 * (7 * 8 + 3 * 4 + 128) + 64 + 4 * cap
     assert plan(2048, 2048, 2000)[0] == 1 and plan(2049, 2048, 2000)[0] == 0  # 16384 workgroups of 256 pixels is the limit
-    with_objects = plan(512, 2048, 2000, objects=3)  # round 4: a tile of a scene with objects is sliced too, its groups carrying
-    assert with_objects[0] == 1 and with_objects[1] == groups and with_objects[2] == cap  # their candidate lists (96 entries each)
-    assert with_objects[3] == nbytes + 256 + groups * (96 * (4 * 8 + 4) + 16)
-    assert plan(4096, 2048, 2000, objects=3)[0] == 0, "the whole frame of a scene with objects: the lean march + the general tracer"
+    assert plan(512, 2048, 2000, objects=3)[0] == 0, "scenes with objects keep the small-launch march (sliced only when forced)"
     assert plan(64, 64, slice_steps - 2)[0] == 0 and plan(64, 64, slice_steps - 1)[0] == 1  # rays of one slice are not sliced
     ragged = plan(150, 61, 2308)
     assert ragged[1] == (150 * 61 + 63) // 64 and ragged[3] == ragged[1] * 64 * 196 + 64 + 4 * ragged[2]

@@ -6,6 +6,7 @@
 // Compile with -ffp-contract=off: the CPU checker (oracle/) executes the same operation sequence
 // without FMA contraction and results are compared bit-for-bit.
 #pragma once
+#include <cstddef>
 
 #include <stdint.h>
 
@@ -48,36 +49,40 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // dh = h - hb.  Linear segments (cubic == 0) use the closed-form hydrostatic pressure, cubic ones a 5-point
 // Gauss-Legendre quadrature of dh/T.
 // Any number of segments (the reference's AtmosphereDef holds `Vec`s: README.md:283-323, params.rs:453-454): the table is a
-// 32-byte header followed, in the same allocation, by its n segments — one 120-byte record each, so the parameters of the
+// 32-byte header followed, in the same allocation, by its n segments — one 128-byte record each, so the parameters of the
 // wave-uniform hinted layer are one run of scalar loads and a per-lane layer is one gather base.
 struct AtmSeg {
+  // ---- the first 64 bytes are what one RK4 stage of the marching kernels reads on its normal path: ONE scalar load ----
+  // the TIGHT part [tight_lo, tight_hi) of the certified interval (empty: lo = +inf): the kernels vote on it first — the votes of
+  // dm_div3 and the v_rcp_f64 of Z and n go — and on [safe_lo, safe_hi) only when a lane is outside it
+  double tight_lo, tight_hi;
   double hb;    // reference altitude of the segment
   double tb;    // temperature at hb
+  double rtb;   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
   double pb;    // pressure at hb
   double lapse; // c1 = dT/dh at hb
-  double from;  // segment k >= 1 applies for h >= from
   double expo;  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
-  double c2;
-  double c3;
-  double rtb;   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
+  // ---- the next 24 bytes complete it ----
+  // TIGHT segments: 1/2 - margin, where margin bounds |e_i - e_0| 128 / ln2 for the arguments e of exp at the three evaluation
+  // points of one right-hand side — dm_exp3_main_shared shares its table row among them while the centre's product is at most
+  // this far from an integer (negative: never)
+  double exp_thr;
+  double k_refr; // a copy of AtmTable::k_refr (atm_certify): the stage needs no second load from the header
+  // ATM_SEG_ISOTHERMAL: lapse == 0 (a scalar integer test in the kernels, where the double compare costs a VALU slot per stage).
+  // ATM_SEG_TIGHT (atm_certify): over [tight_lo, tight_hi) the three evaluation points of one ODE right-hand side (1 cm apart) have
+  // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-10.5 — so dm_div3 needs no
+  // vote on its seeds, 2 - Z seeds the reciprocal of Z and 1 - (n - 1) that of n (dm_div3_seeded, dm_div_seeded).
+  int32_t flags;
+  int32_t cubic; // 1: a knot interval of a Spline temperature function
+  // ---- the rest: the fall-back vote, the layer search, Spline segments ----
   // atm_certify: the part [safe_lo, safe_hi) of the segment over which T, p, p/T, Z and n are PROVEN to stay inside the operand range of
   // the GPU's division / square-root shortcuts (detmath.h); empty (lo = +inf) when nothing can be proven.  An evaluation outside it
   // takes the IEEE operations, so a pathological atmosphere (a spline that overshoots to 30 K, a pressure of 1e308 Pa) is slower but
   // still bit-identical to the host.
   double safe_lo, safe_hi;
-  int32_t cubic; // 1: a knot interval of a Spline temperature function
-  // ATM_SEG_ISOTHERMAL: lapse == 0 (a scalar integer test in the kernels, where the double compare costs a VALU slot per stage).
-  // ATM_SEG_TIGHT (atm_certify): over [safe_lo, safe_hi) the three evaluation points of one ODE right-hand side (1 cm apart) have
-  // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-10.5 — so dm_div3 needs no
-  // vote on its seeds, 2 - Z seeds the reciprocal of Z and 1 - (n - 1) that of n (dm_div3_seeded, dm_div_seeded).
-  int32_t flags;
-  // TIGHT segments: 1/2 - margin, where margin bounds |e_i - e_0| 128 / ln2 for the arguments e of exp at the three evaluation
-  // points of one right-hand side — dm_exp3_main_shared shares its table row among them while the centre's product is at most
-  // this far from an integer (negative: never)
-  double exp_thr;
-  // the TIGHT part [tight_lo, tight_hi) of the certified interval (empty: lo = +inf): the kernels vote on it first — the votes of
-  // dm_div3 and the v_rcp_f64 of Z and n go — and on [safe_lo, safe_hi) only when a lane is outside it
-  double tight_lo, tight_hi;
+  double from;  // segment k >= 1 applies for h >= from
+  double c2;
+  double c3;
 };
 constexpr int32_t ATM_SEG_ISOTHERMAL = 1, ATM_SEG_TIGHT = 2;
 struct AtmTable {
@@ -88,7 +93,7 @@ struct AtmTable {
   ATMRT_HD const AtmSeg& seg(int k) const { return reinterpret_cast<const AtmSeg*>(this + 1)[k]; }
   ATMRT_HD AtmSeg& seg(int k) { return reinterpret_cast<AtmSeg*>(this + 1)[k]; }
 };
-static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 120, "device and host read the table as header + records");
+static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 128 && offsetof(AtmSeg, exp_thr) == 64, "device and host read the table as header + records");
 // the table in the constant address space (it is read-only for a whole launch): wave-uniform indices become scalar loads
 #if defined(__HIPCC__)
 typedef const __attribute__((address_space(4))) AtmTable* AtmConstTable;
@@ -456,6 +461,7 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
     t.seg(k).safe_lo = t.seg(k).tight_lo = dm_inf();
     t.seg(k).safe_hi = t.seg(k).tight_hi = -dm_inf();
     t.seg(k).flags = !t.seg(k).cubic && t.seg(k).lapse == 0.0 ? ATM_SEG_ISOTHERMAL : 0;
+    t.seg(k).k_refr = t.k_refr;
     // the exponents of the three points of one right-hand side: e = expo log(T / tb), log arguments within 2^-21 of one another on
     // a tight segment (+ the rounding of log itself: 4 ulp of a value below 12), or e = expo (h - hb) with h 1 cm apart
     const double ae = dm_fabs(t.seg(k).expo);
@@ -809,11 +815,10 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   const double h1 = h - eps, h2 = h + eps;
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
-  const AtmConstTable ka = atm_const_table(a);
   const AtmConstSeg ks = atm_const_seg(a, ku);
   const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi);
   if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
-    const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n1, n2, q0;
@@ -1221,13 +1226,12 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   const double h = spherical ? a - radius : a, h1 = h - eps, h2 = h + eps;
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   // the table is read-only for the whole launch: reading it through the constant address space makes these scalar loads
-  const AtmConstTable ka = atm_const_table(atm);
   const AtmConstSeg ks = atm_const_seg(atm, ku);
   // the tight part of the hinted layer first (one vote: the normal case), its whole certified part when a lane is outside that
   const bool slope_ok = !(dm_fabs(b) > ACCEL_FAST_MAX_B);
   const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi && slope_ok);
   if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi && slope_ok)) {
-    const double k_refr = ka->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n, n1, n2, q0;

@@ -349,13 +349,14 @@ def main():
                     "lane_utilisation": sq.get("lane_utilisation"), "lane_instructions_per_s": rate,
                     "fp64_issue_peak_per_s": FP64_ISSUE_PEAK, "fp64_flops_per_ray_step": flops,
                     "fp64_flops_per_ray_step_hw_counter": sq.get("fp64_flops_per_ray_step_hw_counter"),
+                    "effective_clock_ghz": sq.get("effective_clock_ghz"),  # GRBM_GUI_ACTIVE / 8 XCDs / the kernel's mean duration under rocprofv3
                     "lane_instructions_per_ray_step_by_kind": sq.get("lane_instructions_per_ray_step_by_kind")}
             if flops:
                 out = {"bound": "fp64_valu", "achieved": flops * steps_per_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                        "frac": flops * steps_per_s / 1e12 / FP64_VALU_PEAK_TF, "issue_slot_frac": rate / FP64_ISSUE_PEAK, "traffic": traffic,
                        "note": "achieved = FP64 flops per ray-step (SQ_INSTS_VALU_ADD/MUL/FMA/TRANS_F64 of this build's cached rocprofv3 passes; "
                                "FMA = 2) x live ray-steps/s; issue_slot_frac = all VALU lane-instructions/s over the FP64 issue peak: the "
-                               "pipes are that full, of which 72 % FP64 arithmetic — the rest is table-index integer work, compares, moves",
+                               "pipes are that full, of which 83 % FP64 arithmetic — the rest is table-index integer work, compares, moves",
                        "valu": valu, "hbm": hbm}
             else:  # counters from before the instruction-mix passes existed: issue slots only, labelled as such
                 out = {"bound": "fp64_valu_issue", "achieved": rate / 1e12, "peak": FP64_ISSUE_PEAK / 1e12, "unit": "T lane-instructions/s",

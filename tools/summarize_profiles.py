@@ -104,10 +104,21 @@ def main():
         if os.path.exists(p) and bench_line(p):
             steps[frag] = bench_line(p)["ray_steps_per_frame"]
             frames[frag] = bench_line(p)["steps"] + bench_line(p)["warmup"]
+    # mean launch duration of every kernel from rocprofv3's own kernel_stats.csv of the trace passes (AverageNs)
+    avg_ns = {}
+    for gen in ("Rectilinear", "Fast", "InterpolatingRectilinear"):
+        for f in glob.glob(os.path.join(src, f"trace_{gen}", "**", "*kernel_stats.csv"), recursive=True)[:1]:
+            for row in csv.DictReader(open(f, newline="")):
+                m = KERNEL.search(row["Name"])
+                if m and m.group(1) not in avg_ns:
+                    avg_ns[m.group(1)] = float(row["AverageNs"])
     for k, v in sq.items():
         if "GRBM_GUI_ACTIVE" in v and "SQ_ACTIVE_INST_VALU" in v:
             v["kernel_cycles"] = v["GRBM_GUI_ACTIVE"] / N_XCD
             v["valu_busy_frac"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / v["kernel_cycles"]
+            if k in avg_ns:  # the clock the kernel actually ran at: GRBM_GUI_ACTIVE / 8 XCDs / its mean duration
+                v["kernel_ms_rocprof"] = avg_ns[k] / 1e6
+                v["effective_clock_ghz"] = v["kernel_cycles"] / avg_ns[k]
         if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU"):
             v["lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
         for frag, n in steps.items():

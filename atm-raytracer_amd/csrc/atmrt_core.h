@@ -781,8 +781,7 @@ struct AtmLayerCache {
   double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
 };
 template <bool CUBIC>
-__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified,
-                                                     bool idle = false) {
+__device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified) {
   const int ku = __builtin_amdgcn_readfirstlane(hint);
   if (ku != cache.k) { // wave-uniform
     const AtmConstSeg ks = atm_const_seg(a, ku);
@@ -792,7 +791,7 @@ __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayer
     cache.lapse = ks->lapse, cache.c2 = ks->c2, cache.c3 = ks->c3, cache.expo = ks->expo;
     cache.k_refr = atm_const_table(a)->k_refr;
   }
-  if (__all(idle || (h >= cache.safe_lo && h < cache.safe_hi))) { // (an idle lane's value is discarded: it does not vote)
+  if (__all(h >= cache.safe_lo && h < cache.safe_hi)) {
     certified = true;
     return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
   }

@@ -117,7 +117,16 @@ struct atmrt_ctx {
   bool have_params = false;
   atmrt_params_t params{};       // as the caller set them (a rank of a shared frame: the WHOLE image; its columns are in `comm`)
   atmrt::AtmDef atm_def;
+  std::vector<uint8_t> atm_def_bytes; // the definition as it was last set, byte for byte (atmrt_set_atmosphere)
+  uint64_t atm_def_serial = 0;        // counts its changes
   atmrt::AtmTableBuf atm;
+  struct AtmKey {                     // what the compiled table in `atm` / d_atm was built from (prepare_frame)
+    uint64_t def_serial;
+    double wavelength, step, radius;
+    int32_t spherical;
+    int32_t _pad = 0;
+  } atm_key{};
+  bool atm_key_valid = false;
   atmrt::Earth earth{};
   atmrt::Pinhole pinhole{};
   std::vector<double> xs;

@@ -38,13 +38,13 @@ struct OctetRK4 {
 
   // n and dn at position `pos` for both stage groups: this lane evaluates its share, everyone receives both results
   __device__ __forceinline__ void eval(bool spherical, double radius, double pos_a, double pos_b, int& hint, AtmLayerCache& cache,
-                                       double& n_a, double& dn_a, double& n_b, double& dn_b, bool& certified, bool idle) const {
+                                       double& n_a, double& dn_a, double& n_b, double& dn_b, bool& certified) const {
     const double eps = 0.01;
     const double pos = (sub & 4) ? pos_b : pos_a;
     const double h = spherical ? pos - radius : pos;
     const int e = sub & 3;
     const double hh = e == 1 ? h - eps : e == 2 ? h + eps : h;
-    const double nv = refr_n_speculative<CUBIC>(atm, cache, hh, hint, certified, idle);
+    const double nv = refr_n_speculative<CUBIC>(atm, cache, hh, hint, certified);
     // every lane of a quad: its quad's n(h), n(h - eps), n(h + eps); then dn for the quad's stage, then the other quad's pair
     const double n_q = dpp_move<DPP_QUAD_BCAST0>(nv);
     const double q1 = dpp_move<DPP_QUAD_BCAST1>(nv), q2 = dpp_move<DPP_QUAD_BCAST2>(nv);
@@ -67,13 +67,8 @@ struct OctetRK4 {
   // k_1a is the start state and each later slope comes from exact earlier stages, so if all four pass all four stages were exact.
   // Otherwise (a wavefront straddling a layer boundary for a few steps; a pathological atmosphere) the step is thrown away and
   // repeated by the serial stepper with its per-stage guards.  One vote per step on this kernel's dependent chain.
-  // `idle`: this lane's row has finished — it takes part in the shuffles, its results are thrown away and its certificate does not
-  // count in the vote (left to run, a ray that ended below -1000 m keeps descending and leaves the certified part of the lowest
-  // layer a few steps later: from then on every step of its whole wavefront would fail the vote and be repeated serially).  What
-  // an idle lane computes outside a certified interval is garbage of no consequence: every table index is masked, atm_layer maps
-  // NaN to layer 0.
   __device__ __forceinline__ RayState next(Stepper& s, AtmLayerCache& cache, bool spherical, double radius, bool straight, double step,
-                                           bool idle, bool& tame) const {
+                                           bool& tame) const {
     if (straight) return stepper_next_with(s, spherical, radius, true, step, SerialAccel<CUBIC>{atm}, tame);
     const double d = spherical ? step / radius : step;
     const double half = 0.5 * d, sixth = d / 6.0;
@@ -82,18 +77,18 @@ struct OctetRK4 {
     double n1, dn1, n2, dn2, n3, dn3, n4, dn4;
     bool cert12, cert34; // per lane
     const double k1a = b;
-    eval(spherical, radius, a, a + half * k1a, s.hint, cache, n1, dn1, n2, dn2, cert12, idle);
+    eval(spherical, radius, a, a + half * k1a, s.hint, cache, n1, dn1, n2, dn2, cert12);
     const double k1b = accel(spherical, a, b, n1, dn1);
     const double k2a = b + half * k1b;
     const double k2b = accel(spherical, a + half * k1a, k2a, n2, dn2);
     const double k3a = b + half * k2b;
-    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, cache, n3, dn3, n4, dn4, cert34, idle);
+    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, cache, n3, dn3, n4, dn4, cert34);
     const double k3b = accel(spherical, a + half * k2a, k3a, n3, dn3);
     const double k4a = b + d * k3b;
     const double k4b = accel(spherical, a + d * k3a, k4a, n4, dn4);
     const bool slopes_ok = !(dm_fabs(k1a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k2a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k3a) > ACCEL_FAST_MAX_B) &&
                            !(dm_fabs(k4a) > ACCEL_FAST_MAX_B);
-    if (!__all(idle || (slopes_ok && cert12 && cert34))) {
+    if (!__all(slopes_ok && cert12 && cert34)) {
       s.hint = hint0;
       return stepper_next_with(s, spherical, radius, false, step, SerialAccel<CUBIC>{atm}, tame);
     }
@@ -166,9 +161,9 @@ __global__ __launch_bounds__(64) void k_fast_paths(Frame f, double* __restrict__
   AtmLayerCache cache; // the hinted layer's parameters, wave-uniform, read again only when the layer changes
   for (int i = i_begin; i < i_last; i++) {
     bool tame;
-    RayState st = rk4.next(s, cache, sph, radius, straight, step, done, tame);
+    RayState st = rk4.next(s, cache, sph, radius, straight, step, tame);
     if (straight) tame = __all(calc_dist_in_band(*f.atm, ph) && calc_dist_in_band(*f.atm, st.h));
-    path_length += calc_dist(sph, radius, px, ph, st.x, st.h, tame, f.inv_shape_radius);
+    path_length += calc_dist(sph, radius, px, ph, st.x, st.h, tame); // (dm_div here: dm_div_r's corrections measured 0.08 ms slower on this kernel's chain)
     if (!done) {
       if (writer) {
         pelev[base + n] = st.h;

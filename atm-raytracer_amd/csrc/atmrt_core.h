@@ -42,6 +42,10 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // ---------------------------------------------------------------------------------------------
 // Atmosphere + refractive index (crate atm-refraction 0.6, source absent: published models —
 // US Standard Atmosphere 1976 layers, hydrostatic ideal gas, Ciddor 1996 dry air).
+// EVALUATION ORDER: oracle/atmosphere.c and oracle/stepper.c fix it (the crate's is unknown) and every function here follows them
+// operation for operation — on a Linear segment x = T / tb = fma(lapse / tb, h - hb, 1), T = tb x; Z by two nested fused
+// multiply-adds; dn = (n(h + eps) - n(h - eps)) * 50; the stepper's stage points and sums fused, its spherical right-hand side over
+// one denominator.
 // ---------------------------------------------------------------------------------------------
 
 // The atmosphere compiled into SEGMENTS: a Linear function is one segment, a Spline contributes one segment per knot
@@ -58,7 +62,7 @@ struct AtmSeg {
   double tight_lo, tight_hi;
   double hb;    // reference altitude of the segment
   double tb;    // temperature at hb
-  double rtb;   // RN(1 / tb): lets the GPU form T/tb with dm_div_r (same value as the division)
+  double gtb;   // lapse / tb: T / tb = fma(gtb, h - hb, 1)
   double pb;    // pressure at hb
   double lapse; // c1 = dT/dh at hb
   double expo;  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
@@ -139,20 +143,17 @@ ATMRT_HD double seg_inv_t_integral(double tb, double c1, double c2, double c3, d
 }
 
 // p(h) / pb of segment k
-ATMRT_HD double seg_pressure_ratio(int cubic, double hb, double tb, double c1, double c2, double c3, double expo, double h) {
+ATMRT_HD double seg_pressure_ratio(int cubic, double hb, double tb, double gtb, double c1, double c2, double c3, double expo, double h) {
   if (cubic) return dm_exp(expo * seg_inv_t_integral(tb, c1, c2, c3, h - hb));
-  if (c1 != 0.0) {
-    double t = tb + c1 * (h - hb);
-    return dm_pow(t / tb, expo);
-  }
+  if (c1 != 0.0) return dm_pow(DM_FMA(gtb, h - hb, 1.0), expo);
   return dm_exp(expo * (h - hb));
 }
 ATMRT_HD double atm_pressure_ratio(const AtmTable& a, int k, double h) {
-  return seg_pressure_ratio(a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+  return seg_pressure_ratio(a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
 }
 ATMRT_HD double atm_seg_temperature(const AtmTable& a, int k, double h) {
   if (a.seg(k).cubic) return seg_temperature(a.seg(k).tb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, h - a.seg(k).hb);
-  return a.seg(k).tb + a.seg(k).lapse * (h - a.seg(k).hb);
+  return a.seg(k).tb * DM_FMA(a.seg(k).gtb, h - a.seg(k).hb, 1.0);
 }
 
 // Host storage of a table: the header and its records in one block (what prepare_frame uploads as it is).
@@ -246,6 +247,7 @@ inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTabl
       out.seg(n).hb = x[0];
       out.seg(n).tb = y[0];
       out.seg(n).lapse = (y[1] - y[0]) / hh - hh * (2.0 * m[0] + m[1]) / 6.0; // S'(x0)
+      out.seg(n).gtb = out.seg(n).lapse / out.seg(n).tb;
       n++;
     }
     for (int i = 0; i + 1 < np; i++) {
@@ -270,6 +272,7 @@ inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTabl
       out.seg(n).hb = x[np - 1];
       out.seg(n).tb = y[np - 1];
       out.seg(n).lapse = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0; // S'(x_last)
+      out.seg(n).gtb = out.seg(n).lapse / out.seg(n).tb;
       n++;
     }
     anchored[j] = true;
@@ -286,6 +289,7 @@ inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTabl
       int k = first_seg[jt];
       out.seg(k).hb = jt == 0 ? def.temperature_altitude : out.seg(k).from;
       out.seg(k).tb = def.temperature - out.seg(k).lapse * (def.temperature_altitude - out.seg(k).hb);
+      out.seg(k).gtb = out.seg(k).lapse / out.seg(k).tb;
       anchored[jt] = true;
     }
   }
@@ -300,19 +304,21 @@ inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTabl
         int kl = first_seg[j] - 1;
         out.seg(k).hb = out.seg(k).from;
         out.seg(k).tb = atm_seg_temperature(out, kl, out.seg(k).from);
+        out.seg(k).gtb = out.seg(k).lapse / out.seg(k).tb;
         anchored[j] = true;
       } else if (j + 1 < nf && anchored[j + 1]) { // continuous with the function above at its start altitude
         int ku = first_seg[j + 1];
         double top = def.functions[j + 1].altitude;
         out.seg(k).hb = j == 0 ? top : out.seg(k).from;
         out.seg(k).tb = atm_seg_temperature(out, ku, top) - out.seg(k).lapse * (top - out.seg(k).hb);
+        out.seg(k).gtb = out.seg(k).lapse / out.seg(k).tb;
         anchored[j] = true;
       }
     }
   }
   for (int k = 0; k < n; k++) {
     out.seg(k).expo = out.seg(k).cubic ? -gmr : (out.seg(k).lapse != 0.0 ? -gmr / out.seg(k).lapse : -gmr / out.seg(k).tb);
-    out.seg(k).rtb = 1.0 / out.seg(k).tb;
+    out.seg(k).gtb = out.seg(k).lapse / out.seg(k).tb; // (set where tb was: the anchoring above evaluates temperatures)
   }
   // ---- pressure: chain outwards from the pressure fixed point
   int jp = atm_layer(out, def.pressure_altitude);
@@ -392,8 +398,8 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
     if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
     // p / pb = exp(e) with e = expo * log(T / tb) (or expo * (h - hb) on an isothermal segment): monotone in h, so the end points
     // bound it.  Within 1e-280 .. 1e280 means |e| <= 645 < 700 at every point of the interval: the certified evaluation may call
-    // the main branch of exp without asking (refr_n_layer3) — and T / tb, a ratio of two temperatures in 1 .. 1e5 K, is a positive
-    // normal number: the main branch of log likewise.
+    // the main branch of exp without asking (refr_n_layer3) — and x = fma(gtb, h - hb, 1), monotone in h and with T = tb x in 1 .. 1e5 K
+    // at both ends, is a positive normal number (>= 1e-5 (1 - 2^-52)): the main branch of log likewise.
     const double r0 = atm_pressure_ratio(t, k, lo), r1 = atm_pressure_ratio(t, k, hi);
     if (!(r0 >= 1.0e-280 && r0 <= 1.0e280 && r1 >= 1.0e-280 && r1 <= 1.0e280)) return false;
     const double p0 = pb * r0, p1 = pb * r1;
@@ -409,8 +415,9 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
 }
 
 // The extra bounds of a TIGHT segment over its certified interval [lo, hi] (Linear segments only; atm_interval_certified holds):
-//   (1) |lapse| eps / Tmin <= 2^-21: the temperatures at h, h -+ eps are within 2^-21 (1 + 2^-40) of one another after rounding,
-//       half of what dm_div3's seeds tolerate (2^-20);
+//   (1) |lapse| eps / Tmin <= 2^-21: the arguments x = fma(gtb, h - hb, 1) of log at h, h -+ eps differ by |gtb| eps = |lapse| eps / tb,
+//       relative to x = T / tb that is |lapse| eps / T; with the rounding of each x (2^-53 absolute, x >= 1e-5) they and the
+//       temperatures T = tb x are within 2^-21 (1 + 2^-35) of one another, half of what dm_div3's seeds tolerate (2^-20);
 //   (2) the same for the compressibilities: |dZ| / Z <= 2 |dZ| with |dZ| <= d_pt ptmax amax + ptmax |lapse| eps (|a1| + 2 tm a2)
 //       + 2 d_pt ptmax^2 d, where d_pt = (g0 M / R + |lapse|) eps / Tmin bounds the relative change of p / T over eps
 //       (p is a power or an exponential of h with logarithmic derivative g0 M / (R T));
@@ -569,13 +576,21 @@ ATMRT_HD bool wave_all(bool p) {
 #endif
 }
 
+constexpr double REFR_INV_2EPS = 50.0; // 0.5 / eps of the central difference dn/dh (eps = 0.01 m; the quotient is 50 exactly)
+// Ciddor's compressibility of dry air, Z = 1 - pt (a0 + a1 t + a2 t^2) + pt^2 d with pt = p / T and t = T - 273.15, as
+// oracle/atmosphere.c evaluates it: fma(pt, fma(pt, d, -A), 1), A = fma(t, fma(t, a2, a1), a0).  -A is formed directly (every
+// constant negated: the same magnitude bit for bit, rounding to nearest is symmetric), so no negation is issued.
+ATMRT_HD double ciddor_z(double pt, double t) {
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
+  const double na = DM_FMA_VVS(t, DM_FMA_VSV(t, -a2, -a1), -a0);
+  return DM_FMA(pt, DM_FMA_VSV(pt, d, na), 1.0);
+}
 // Ciddor's (n - 1) = K (p/T) / Z for dry air
 template <bool FAST = false>
 ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
-  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   double t = temp - 273.15;
   double pt = div_sel<FAST>(p, temp);
-  double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
+  double z = ciddor_z(pt, t);
   return 1.0 + div_sel<FAST>(k_refr * pt, z);
 }
 
@@ -583,13 +598,9 @@ ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
 // two division sites share their reciprocal refinement across the points (dm_div3)
 ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, double p0, double p1, double p2, double& n0, double& n1,
                             double& n2) {
-  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   double pt0, pt1, pt2;
   dm_div3(p0, t0, p1, t1, p2, t2, &pt0, &pt1, &pt2);
-  const double c0 = t0 - 273.15, c1 = t1 - 273.15, c2 = t2 - 273.15;
-  const double z0 = 1.0 - pt0 * (a0 + c0 * (a1 + c0 * a2)) + pt0 * pt0 * d;
-  const double z1 = 1.0 - pt1 * (a0 + c1 * (a1 + c1 * a2)) + pt1 * pt1 * d;
-  const double z2 = 1.0 - pt2 * (a0 + c2 * (a1 + c2 * a2)) + pt2 * pt2 * d;
+  const double z0 = ciddor_z(pt0, t0 - 273.15), z1 = ciddor_z(pt1, t1 - 273.15), z2 = ciddor_z(pt2, t2 - 273.15);
   double q0, q1, q2;
   dm_div3(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, &q0, &q1, &q2);
   n0 = 1.0 + q0;
@@ -600,13 +611,9 @@ ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, doub
 // the same on a TIGHT segment (AtmSeg::flags): no votes, the reciprocal of Z seeded by 2 - Z; q0 = n0 - 1 seeds the caller's 1 / n0
 ATMRT_HD void refr_from_tp3_tight(double k_refr, double t0, double t1, double t2, double p0, double p1, double p2, double& n0, double& n1,
                                   double& n2, double& q0) {
-  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   double pt0, pt1, pt2;
   dm_div3_seeded(p0, t0, p1, t1, p2, t2, 0, 0.0, &pt0, &pt1, &pt2);
-  const double c0 = t0 - 273.15, c1 = t1 - 273.15, c2 = t2 - 273.15;
-  const double z0 = 1.0 - pt0 * (a0 + c0 * (a1 + c0 * a2)) + pt0 * pt0 * d;
-  const double z1 = 1.0 - pt1 * (a0 + c1 * (a1 + c1 * a2)) + pt1 * pt1 * d;
-  const double z2 = 1.0 - pt2 * (a0 + c2 * (a1 + c2 * a2)) + pt2 * pt2 * d;
+  const double z0 = ciddor_z(pt0, t0 - 273.15), z1 = ciddor_z(pt1, t1 - 273.15), z2 = ciddor_z(pt2, t2 - 273.15);
   double q1, q2;
   dm_div3_seeded(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, 1, 2.0 - z0, &q0, &q1, &q2);
   n0 = 1.0 + q0;
@@ -626,11 +633,12 @@ ATMRT_HD double refr_n_cubic_segment(double k_refr, double hb, double tb, double
 // closed-form path of Linear functions: the stepping kernels are compiled in both variants and the host picks by
 // whether the atmosphere has Spline segments (inlining the quadrature path twelve times per RK4 step costs 9 % on US-76).
 template <bool CUBIC = true, bool FAST = false>
-ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3,
+ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, double gtb, double pb, double lapse, double c2, double c3,
                              double expo, double h) {
   if (CUBIC && cubic) return refr_n_cubic_segment<FAST>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h);
-  double temp = tb + lapse * (h - hb);
-  double ratio = lapse != 0.0 ? dm_pow(div_sel<FAST>(temp, tb), expo) : dm_exp(expo * (h - hb));
+  double x = DM_FMA(gtb, h - hb, 1.0);
+  double temp = tb * x;
+  double ratio = lapse != 0.0 ? dm_pow(x, expo) : dm_exp(expo * (h - hb));
   return refr_from_tp<FAST>(k_refr, temp, pb * ratio);
 }
 
@@ -710,7 +718,7 @@ ATMRT_HD void exp3_tight(double e0, double e1, double e2, double thr, double& r0
 // normal number and |expo log(T / tb)| (|expo (h - hb)| on an isothermal segment) is at most 645, so log and exp take their main
 // branches unasked — the values of refr_n_layer at the three points.
 template <bool CUBIC = true>
-ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr, double hb, double tb, double rtb, double pb, double lapse,
+ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr, double hb, double tb, double gtb, double pb, double lapse,
                             double c2, double c3, double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2, double& q0) {
   if (CUBIC && cubic) {
     n0 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
@@ -718,20 +726,23 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr,
     n2 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h2);
     return;
   }
-  const double t0 = tb + lapse * (h0 - hb), t1 = tb + lapse * (h1 - hb), t2 = tb + lapse * (h2 - hb);
+  (void)lapse;
+  const double d0 = h0 - hb, d1 = h1 - hb, d2 = h2 - hb;
+  const double x0 = DM_FMA(gtb, d0, 1.0), x1 = DM_FMA(gtb, d1, 1.0), x2 = DM_FMA(gtb, d2, 1.0);
+  const double t0 = tb * x0, t1 = tb * x1, t2 = tb * x2;
   double r0, r1, r2;
   if (flags & ATM_SEG_TIGHT) {
-    if (!(flags & ATM_SEG_ISOTHERMAL)) pow3_tight(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, exp_thr, r0, r1, r2);
-    else exp3_tight(expo * (h0 - hb), expo * (h1 - hb), expo * (h2 - hb), exp_thr, r0, r1, r2);
+    if (!(flags & ATM_SEG_ISOTHERMAL)) pow3_tight(x0, x1, x2, expo, exp_thr, r0, r1, r2);
+    else exp3_tight(expo * d0, expo * d1, expo * d2, exp_thr, r0, r1, r2);
     refr_from_tp3_tight(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2, q0);
     return;
   }
   if (!(flags & ATM_SEG_ISOTHERMAL)) {
-    pow3_in_range(dm_div_r(t0, tb, rtb), dm_div_r(t1, tb, rtb), dm_div_r(t2, tb, rtb), expo, r0, r1, r2);
+    pow3_in_range(x0, x1, x2, expo, r0, r1, r2);
   } else {
-    r0 = dm_exp_main(expo * (h0 - hb));
-    r1 = dm_exp_main(expo * (h1 - hb));
-    r2 = dm_exp_main(expo * (h2 - hb));
+    r0 = dm_exp_main(expo * d0);
+    r1 = dm_exp_main(expo * d1);
+    r2 = dm_exp_main(expo * d2);
   }
   refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
 }
@@ -740,13 +751,13 @@ ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr,
 // generic evaluation, valid for any atmosphere at any altitude.
 ATMRT_HD double refr_n(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
-  return refr_n_layer(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+  return refr_n_layer(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
 }
 ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   const double eps = 0.01;
   double n1 = refr_n(a, h - eps);
   double n2 = refr_n(a, h + eps);
-  return (n2 - n1) / (2.0 * eps);
+  return (n2 - n1) * REFR_INV_2EPS;
 }
 
 // Environment::n(h) for a point INSIDE the certified part of its segment: shortcut divisions, and log / exp by their main branches
@@ -754,15 +765,16 @@ ATMRT_HD double refr_dn(const AtmTable& a, double h) {
 // Straight-line code.  For a point outside, the result is garbage of no consequence (every table index is masked): callers
 // discard it (refr_n_speculative's `certified` flag).
 template <bool CUBIC>
-ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double tb, double pb, double lapse, double c2, double c3,
+ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double tb, double gtb, double pb, double lapse, double c2, double c3,
                                      double expo, double h) {
   if (CUBIC && cubic) {
     const double temp = seg_temperature(tb, lapse, c2, c3, h - hb);
     const double p = pb * dm_exp_main(expo * seg_inv_t_integral(tb, lapse, c2, c3, h - hb));
     return refr_from_tp<true>(k_refr, temp, p);
   }
-  const double temp = tb + lapse * (h - hb);
-  const double e = lapse != 0.0 ? expo * dm_log_core_pow(dm_div(temp, tb)) : expo * (h - hb);
+  const double x = DM_FMA(gtb, h - hb, 1.0);
+  const double temp = tb * x;
+  const double e = lapse != 0.0 ? expo * dm_log_core_pow(x) : expo * (h - hb);
   return refr_from_tp<true>(k_refr, temp, pb * dm_exp_main(e));
 }
 
@@ -778,7 +790,7 @@ ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double
 struct AtmLayerCache {
   int k = -1;
   int cubic = 0;
-  double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
+  double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, gtb = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
 };
 template <bool CUBIC>
 __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified) {
@@ -787,19 +799,19 @@ __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayer
     const AtmConstSeg ks = atm_const_seg(a, ku);
     cache.k = ku;
     cache.cubic = ks->cubic;
-    cache.safe_lo = ks->safe_lo, cache.safe_hi = ks->safe_hi, cache.hb = ks->hb, cache.tb = ks->tb, cache.pb = ks->pb;
+    cache.safe_lo = ks->safe_lo, cache.safe_hi = ks->safe_hi, cache.hb = ks->hb, cache.tb = ks->tb, cache.gtb = ks->gtb, cache.pb = ks->pb;
     cache.lapse = ks->lapse, cache.c2 = ks->c2, cache.c3 = ks->c3, cache.expo = ks->expo;
     cache.k_refr = atm_const_table(a)->k_refr;
   }
   if (__all(h >= cache.safe_lo && h < cache.safe_hi)) {
     certified = true;
-    return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
+    return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.gtb, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
   }
   const int k = atm_layer(a, h);
   hint = k;
   const AtmSeg& sg = a.seg(k);
   certified = h >= sg.safe_lo && h < sg.safe_hi;
-  return refr_n_layer_inrange<CUBIC>(a.k_refr, sg.cubic, sg.hb, sg.tb, sg.pb, sg.lapse, sg.c2, sg.c3, sg.expo, h);
+  return refr_n_layer_inrange<CUBIC>(a.k_refr, sg.cubic, sg.hb, sg.tb, sg.gtb, sg.pb, sg.lapse, sg.c2, sg.c3, sg.expo, h);
 }
 #endif
 
@@ -817,12 +829,12 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   const AtmConstSeg ks = atm_const_seg(a, ku);
   const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi);
   if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
-    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, gtb = ks->gtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n1, n2, q0;
-    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
-    dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, gtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
+    dn = (n2 - n1) * REFR_INV_2EPS;
     return true;
   }
   // generic: per-lane layer search, IEEE operations.  The hint follows the lane, so that the fast path resumes once the
@@ -830,11 +842,11 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   {
     const int k = atm_layer(a, h);
     hint = k;
-    n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+    n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
     const int k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
-    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
-    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
-    dn = (n2 - n1) / (2.0 * eps);
+    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).gtb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
+    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).gtb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
+    dn = (n2 - n1) * REFR_INV_2EPS;
     return false;
   }
 #else
@@ -1186,15 +1198,20 @@ ATMRT_HD void stepper_init(Stepper& s, bool spherical, double radius, double h0,
 // a = radius + h >= 1000 m, <= 2^25 m, both part of the certificate) and |b| <= 2^100, which keeps every operand and quotient
 // of the three divisions inside dm_div's range; anything else divides in IEEE.
 constexpr double ACCEL_FAST_MAX_B = 1.2676506002282294e30; // 2^100
+// oracle/stepper.c accel_sph / accel_flat: the spherical form over one denominator, r'' = r + (2 r'^2 n + (r^2 + r'^2) r n') / (r n).
+// FAST operand ranges: numerator terms <= 2^201 2^9 and 2^201 2^25 2^15, denominator in [1000, 2^34].
 template <bool FAST>
 ATMRT_HD double accel_rhs(bool spherical, double a, double b, double n, double dn) {
-  if (spherical) return a + div_sel<FAST>(2.0 * b * b, a) + div_sel<FAST>((a * a + b * b) * dn, n);
-  return div_sel<FAST>((1.0 + b * b) * dn, n);
+  if (spherical) {
+    const double b2 = b * b, s = DM_FMA(a, a, b2);
+    return a + div_sel<FAST>(DM_FMA(b2 + b2, n, s * a * dn), a * n);
+  }
+  return div_sel<FAST>(DM_FMA(b, b, 1.0) * dn, n);
 }
-// the same on a TIGHT segment: q = n - 1 <= 2^-10.5, so 1 - q is a seed of 1 / n with error q^2 <= 2^-21 (dm_div_seeded)
+// the flat form on a TIGHT segment: q = n - 1 <= 2^-10.5, so 1 - q is a seed of 1 / n with error q^2 <= 2^-21 (dm_div_seeded)
 ATMRT_HD double accel_rhs_tight(bool spherical, double a, double b, double n, double q, double dn) {
-  if (spherical) return a + dm_div(2.0 * b * b, a) + dm_div_seeded((a * a + b * b) * dn, n, 1.0 - q);
-  return dm_div_seeded((1.0 + b * b) * dn, n, 1.0 - q);
+  if (spherical) return accel_rhs<true>(true, a, b, n, dn);
+  return dm_div_seeded(DM_FMA(b, b, 1.0) * dn, n, 1.0 - q);
 }
 // The generic right-hand side: per-lane layer search, IEEE operations — any atmosphere, any state.  On the GPU it runs for the few
 // steps in which a wavefront straddles a layer boundary, and all the time only in pathological atmospheres.  (Inline: as a call it
@@ -1205,10 +1222,10 @@ ATMRT_HD double ray_accel_generic(const AtmTable& a, bool spherical, double radi
   const double h = spherical ? pa - radius : pa, h1 = h - eps, h2 = h + eps;
   const int k = atm_layer(a, h), k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
   hint = k; // the hint follows the lane, so that the fast path resumes once the wavefront is back inside one certified interval
-  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
-  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
-  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
-  const double dn = (n2 - n1) / (2.0 * eps);
+  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).gtb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
+  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).gtb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
+  const double dn = (n2 - n1) * REFR_INV_2EPS;
   return accel_rhs<false>(spherical, pa, pb, n, dn);
 }
 
@@ -1230,12 +1247,12 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   const bool slope_ok = !(dm_fabs(b) > ACCEL_FAST_MAX_B);
   const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi && slope_ok);
   if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi && slope_ok)) {
-    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, rtb = ks->rtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, gtb = ks->gtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n, n1, n2, q0;
-    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, rtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
-    const double dn = dm_div_r(n2 - n1, 2.0 * eps, 1.0 / (2.0 * eps));
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, gtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
+    const double dn = (n2 - n1) * REFR_INV_2EPS;
     fast = true;
     if ((flags & ATM_SEG_TIGHT) && !(CUBIC && cubic)) return accel_rhs_tight(spherical, a, b, n, q0, dn);
     return accel_rhs<true>(spherical, a, b, n, dn);
@@ -1249,6 +1266,10 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
 // altitude then lies in a certified interval (radius + h >= 1000 m) and every stage slope is at most 2^100, so that the altitude
 // change of the step is below 2^100 step: enough for calc_dist's shortcuts without another look at the end state.  Straight rays
 // (closed form, no stages) report false; their callers test the altitudes (calc_dist_in_band).
+// y + h/6 (k1 + 2 k2 + 2 k3 + k4) as oracle/stepper.c forms it
+ATMRT_HD double rk4_sum(double y, double sixth, double k1, double k2, double k3, double k4) {
+  return DM_FMA(sixth, DM_FMA(2.0, k3, DM_FMA(2.0, k2, k1)) + k4, y);
+}
 template <class Accel>
 ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, bool straight, double step, const Accel& accel, bool& tame) {
   RayState out;
@@ -1274,15 +1295,15 @@ ATMRT_HD RayState stepper_next_with(Stepper& s, bool spherical, double radius, b
   bool f1, f2, f3, f4;
   double k1a = b;
   double k1b = accel(spherical, radius, a, b, s.hint, f1);
-  double k2a = b + half * k1b;
-  double k2b = accel(spherical, radius, a + half * k1a, k2a, s.hint, f2);
-  double k3a = b + half * k2b;
-  double k3b = accel(spherical, radius, a + half * k2a, k3a, s.hint, f3);
-  double k4a = b + d * k3b;
-  double k4b = accel(spherical, radius, a + d * k3a, k4a, s.hint, f4);
+  double k2a = DM_FMA(half, k1b, b);
+  double k2b = accel(spherical, radius, DM_FMA(half, k1a, a), k2a, s.hint, f2);
+  double k3a = DM_FMA(half, k2b, b);
+  double k3b = accel(spherical, radius, DM_FMA(half, k2a, a), k3a, s.hint, f3);
+  double k4a = DM_FMA(d, k3b, b);
+  double k4b = accel(spherical, radius, DM_FMA(d, k3a, a), k4a, s.hint, f4);
   tame = f1 && f2 && f3 && f4;
-  s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
-  s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
+  s.a = rk4_sum(a, sixth, k1a, k2a, k3a, k4a);
+  s.b = rk4_sum(b, sixth, k1b, k2b, k3b, k4b);
   s.x = s.x + step;
   out.x = s.x;
   if (spherical) {

@@ -49,7 +49,7 @@ struct OctetRK4 {
     const double n_q = dpp_move<DPP_QUAD_BCAST0>(nv);
     const double q1 = dpp_move<DPP_QUAD_BCAST1>(nv), q2 = dpp_move<DPP_QUAD_BCAST2>(nv);
     // shortcut divisions whether or not every lane was certified: next() discards the step if one was not
-    const double dn_q = dm_div(q2 - q1, 2.0 * eps);
+    const double dn_q = (q2 - q1) * REFR_INV_2EPS;
     const double n_o = dpp_move<DPP_ROW_HALF_MIRROR>(n_q), dn_o = dpp_move<DPP_ROW_HALF_MIRROR>(dn_q);
     const bool second = (sub & 4) != 0; // this lane's quad serves stage group b
     n_a = second ? n_o : n_q;
@@ -77,15 +77,17 @@ struct OctetRK4 {
     double n1, dn1, n2, dn2, n3, dn3, n4, dn4;
     bool cert12, cert34; // per lane
     const double k1a = b;
-    eval(spherical, radius, a, a + half * k1a, s.hint, cache, n1, dn1, n2, dn2, cert12);
+    const double a2 = DM_FMA(half, k1a, a);
+    eval(spherical, radius, a, a2, s.hint, cache, n1, dn1, n2, dn2, cert12);
     const double k1b = accel(spherical, a, b, n1, dn1);
-    const double k2a = b + half * k1b;
-    const double k2b = accel(spherical, a + half * k1a, k2a, n2, dn2);
-    const double k3a = b + half * k2b;
-    eval(spherical, radius, a + half * k2a, a + d * k3a, s.hint, cache, n3, dn3, n4, dn4, cert34);
-    const double k3b = accel(spherical, a + half * k2a, k3a, n3, dn3);
-    const double k4a = b + d * k3b;
-    const double k4b = accel(spherical, a + d * k3a, k4a, n4, dn4);
+    const double k2a = DM_FMA(half, k1b, b);
+    const double k2b = accel(spherical, a2, k2a, n2, dn2);
+    const double k3a = DM_FMA(half, k2b, b);
+    const double a3 = DM_FMA(half, k2a, a), a4 = DM_FMA(d, k3a, a);
+    eval(spherical, radius, a3, a4, s.hint, cache, n3, dn3, n4, dn4, cert34);
+    const double k3b = accel(spherical, a3, k3a, n3, dn3);
+    const double k4a = DM_FMA(d, k3b, b);
+    const double k4b = accel(spherical, a4, k4a, n4, dn4);
     const bool slopes_ok = !(dm_fabs(k1a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k2a) > ACCEL_FAST_MAX_B) && !(dm_fabs(k3a) > ACCEL_FAST_MAX_B) &&
                            !(dm_fabs(k4a) > ACCEL_FAST_MAX_B);
     if (!__all(slopes_ok && cert12 && cert34)) {
@@ -93,8 +95,8 @@ struct OctetRK4 {
       return stepper_next_with(s, spherical, radius, false, step, SerialAccel<CUBIC>{atm}, tame);
     }
     tame = true;
-    s.a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
-    s.b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
+    s.a = rk4_sum(a, sixth, k1a, k2a, k3a, k4a);
+    s.b = rk4_sum(b, sixth, k1b, k2b, k3b, k4b);
     s.x = s.x + step;
     RayState out;
     out.x = s.x;

@@ -13,7 +13,14 @@
  *     g0 = 9.80665 m/s2, M = 0.0289644 kg/mol, R* = 8.31432 J/(mol K);
  *   - refractive index: Ciddor (Appl. Opt. 35, 1566, 1996) as documented by NIST's Engineering
  *     Metrology Toolbox, dry air (the YAML schema has no humidity), x_CO2 = 450 umol/mol;
- *   - dn/dh: central difference with eps = 0.01 m.
+ *   - dn/dh: central difference with eps = 0.01 m, (n(h + eps) - n(h - eps)) * (0.5 / eps)  (0.5 / 0.01 is 50.0 exactly).
+ * EVALUATION ORDER (round 4).  The crate's expression order is unknown, so the roundings inside these formulas are this build's to
+ * fix; they are fixed HERE, and the product follows bit for bit.  Where the published formula has the shape a*b + c it is one fused
+ * multiply-add (C99 fma, exactly rounded in either flavour):
+ *     dh = h - hb;  x = T / tb = fma(lapse / tb, dh, 1);  T = tb x  (the barometric formula's own variable, p = pb x^expo);
+ *     Z = fma(pt, fma(pt, d, -A), 1),  A = fma(t, fma(t, a2, a1), a0),  pt = p / T,  t = T - 273.15;   n = 1 + k pt / Z.
+ * Against the round-3 order (every operation rounded separately, T / tb by division) the outputs of a frame move by rounding
+ * errors only: tests/test_oracle.py::test_fused_evaluation_order_moves_results_by_rounding_only holds the measured bound.
  */
 #include "oracle.h"
 #include "oracle_math.h"
@@ -58,7 +65,7 @@ static double cubic_temperature(const oracle_env_atm* a, int k, double dh) {
 
 static double seg_temperature(const oracle_env_atm* a, int k, double h) {
   if (a->cubic[k]) return cubic_temperature(a, k, h - a->hb[k]);
-  return a->tb[k] + a->lapse[k] * (h - a->hb[k]);
+  return a->tb[k] * om_fma(a->lapse[k] / a->tb[k], h - a->hb[k], 1.0);
 }
 
 /* Int_{hb}^{hb+dh} dh'/T(h'): 5-point Gauss-Legendre */
@@ -77,9 +84,9 @@ static double inv_t_integral(const oracle_env_atm* a, int k, double dh) {
 /* p(h)/pb of segment k */
 static double pressure_ratio(const oracle_env_atm* a, int k, double h) {
   if (a->cubic[k]) return om_exp(a->expo[k] * inv_t_integral(a, k, h - a->hb[k]));
-  if (a->lapse[k] != 0.0) {
-    double t = a->tb[k] + a->lapse[k] * (h - a->hb[k]);
-    return om_pow(t / a->tb[k], a->expo[k]);
+  if (a->lapse[k] != 0.0) { /* T / tb = 1 + (lapse / tb) (h - hb) */
+    double x = om_fma(a->lapse[k] / a->tb[k], h - a->hb[k], 1.0);
+    return om_pow(x, a->expo[k]);
   }
   return om_exp(a->expo[k] * (h - a->hb[k]));
 }
@@ -290,7 +297,8 @@ double oracle_n(const oracle_env_atm* a, double h) {
   double p = a->pb[k] * pressure_ratio(a, k, h);
   double t = temp - 273.15;
   double pt = p / temp;
-  double z = 1.0 - pt * (a0 + t * (a1 + t * a2)) + pt * pt * d;
+  double aa = om_fma(t, om_fma(t, a2, a1), a0);
+  double z = om_fma(pt, om_fma(pt, d, -aa), 1.0); /* 1 - pt (a0 + a1 t + a2 t^2) + pt^2 d */
   return 1.0 + a->k_refr * pt / z;
 }
 
@@ -298,5 +306,5 @@ double oracle_dn(const oracle_env_atm* a, double h) {
   const double eps = 0.01;
   double n1 = oracle_n(a, h - eps);
   double n2 = oracle_n(a, h + eps);
-  return (n2 - n1) / (2.0 * eps);
+  return (n2 - n1) * (0.5 / eps);
 }

@@ -26,6 +26,7 @@
 #define om_sqrt sqrt
 #define om_floor floor
 #define om_fabs fabs
+#define om_fma fma
 #define OM_PI 3.14159265358979323846
 #define OM_FLAVOUR "libm"
 #else
@@ -42,6 +43,7 @@
 #define om_sqrt dm_sqrt
 #define om_floor dm_floor
 #define om_fabs dm_fabs
+#define om_fma(a, b, c) __builtin_fma((a), (b), (c))
 #define OM_PI DM_PI
 #define OM_FLAVOUR "det"
 #endif

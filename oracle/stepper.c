@@ -10,6 +10,9 @@
  *          r'' = r + 2 r'^2 / r + (r^2 + r'^2) n'(h)/n(h),                   r'(0) = r0 tan(ang)
  *   straight: flat h = h0 + x tan(ang);  sphere r = r0 cos(ang)/cos(ang + x/R).
  * Integrator: classical RK4 with step `step` in x (d phi = step / R); x accumulates by `x += step`.
+ * Evaluation order (round 4; the crate's is unknown, see atmosphere.c): stage points and the final combination are fused
+ * multiply-adds, and the spherical right-hand side is taken over ONE common denominator,
+ *          r'' = r + (2 r'^2 n + (r^2 + r'^2) r n') / (r n).
  */
 #include "oracle.h"
 #include "oracle_math.h"
@@ -36,14 +39,17 @@ void oracle_stepper_init(oracle_stepper* s, const oracle_env_atm* atm, int spher
 static double accel_flat(const oracle_env_atm* atm, double h, double v) {
   double n = oracle_n(atm, h);
   double dn = oracle_dn(atm, h);
-  return (1.0 + v * v) * dn / n;
+  return om_fma(v, v, 1.0) * dn / n;
 }
 
 static double accel_sph(const oracle_env_atm* atm, double radius, double r, double v) {
   double h = r - radius;
   double n = oracle_n(atm, h);
   double dn = oracle_dn(atm, h);
-  return r + 2.0 * v * v / r + (r * r + v * v) * dn / n;
+  double v2 = v * v;
+  double s = om_fma(r, r, v2);
+  double num = om_fma(v2 + v2, n, s * r * dn);
+  return r + num / (r * n);
 }
 
 oracle_ray_state oracle_stepper_next(oracle_stepper* s) {
@@ -71,15 +77,15 @@ oracle_ray_state oracle_stepper_next(oracle_stepper* s) {
 #define ACC(pa, pb) (s->spherical ? accel_sph(s->atm, s->radius, (pa), (pb)) : accel_flat(s->atm, (pa), (pb)))
     k1a = b;
     k1b = ACC(a, b);
-    k2a = b + half * k1b;
-    k2b = ACC(a + half * k1a, k2a);
-    k3a = b + half * k2b;
-    k3b = ACC(a + half * k2a, k3a);
-    k4a = b + d * k3b;
-    k4b = ACC(a + d * k3a, k4a);
+    k2a = om_fma(half, k1b, b);
+    k2b = ACC(om_fma(half, k1a, a), k2a);
+    k3a = om_fma(half, k2b, b);
+    k3b = ACC(om_fma(half, k2a, a), k3a);
+    k4a = om_fma(d, k3b, b);
+    k4b = ACC(om_fma(d, k3a, a), k4a);
 #undef ACC
-    s->a = a + sixth * (k1a + 2.0 * k2a + 2.0 * k3a + k4a);
-    s->b = b + sixth * (k1b + 2.0 * k2b + 2.0 * k3b + k4b);
+    s->a = om_fma(sixth, om_fma(2.0, k3a, om_fma(2.0, k2a, k1a)) + k4a, a);
+    s->b = om_fma(sixth, om_fma(2.0, k3b, om_fma(2.0, k2b, k1b)) + k4b, b);
     s->x = s->x + s->step;
     out.x = s->x;
     if (s->spherical) {

@@ -53,20 +53,18 @@ ATMRT_HD Vec3 cross(Vec3 a, Vec3 b) {
 // dh = h - hb.  Linear segments (cubic == 0) use the closed-form hydrostatic pressure, cubic ones a 5-point
 // Gauss-Legendre quadrature of dh/T.
 // Any number of segments (the reference's AtmosphereDef holds `Vec`s: README.md:283-323, params.rs:453-454): the table is a
-// 32-byte header followed, in the same allocation, by its n segments — one 128-byte record each, so the parameters of the
+// 32-byte header followed, in the same allocation, by its n segments — one 160-byte record each, so the parameters of the
 // wave-uniform hinted layer are one run of scalar loads and a per-lane layer is one gather base.
 struct AtmSeg {
-  // ---- the first 64 bytes are what one RK4 stage of the marching kernels reads on its normal path: ONE scalar load ----
+  // ---- the first 80 bytes are what one RK4 stage of the marching kernels reads on its normal path: one run of scalar loads ----
   // the TIGHT part [tight_lo, tight_hi) of the certified interval (empty: lo = +inf): the kernels vote on it first — the votes of
   // dm_div3 and the v_rcp_f64 of Z and n go — and on [safe_lo, safe_hi) only when a lane is outside it
   double tight_lo, tight_hi;
   double hb;    // reference altitude of the segment
   double tb;    // temperature at hb
-  double gtb;   // lapse / tb: T / tb = fma(gtb, h - hb, 1)
-  double pb;    // pressure at hb
-  double lapse; // c1 = dT/dh at hb
-  double expo;  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
-  // ---- the next 24 bytes complete it ----
+  double gtb;   // lapse / tb: x = T / tb = fma(gtb, h - hb, 1)
+  double ptb;   // pb / tb: the density term p / T at hb
+  double expo1; // the exponent of p / T = ptb x^expo1: expo - 1; on an isothermal segment p / T = ptb exp(expo1 (h - hb)), expo1 = expo
   // TIGHT segments: 1/2 - margin, where margin bounds |e_i - e_0| 128 / ln2 for the arguments e of exp at the three evaluation
   // points of one right-hand side — dm_exp3_main_shared shares its table row among them while the centre's product is at most
   // this far from an integer (negative: never)
@@ -74,19 +72,23 @@ struct AtmSeg {
   double k_refr; // a copy of AtmTable::k_refr (atm_certify): the stage needs no second load from the header
   // ATM_SEG_ISOTHERMAL: lapse == 0 (a scalar integer test in the kernels, where the double compare costs a VALU slot per stage).
   // ATM_SEG_TIGHT (atm_certify): over [tight_lo, tight_hi) the three evaluation points of one ODE right-hand side (1 cm apart) have
-  // temperatures and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-10.5 — so dm_div3 needs no
+  // log arguments and compressibilities within 2^-21 of one another, and n - 1 and |1 - Z| stay below 2^-10.5 — so dm_div3 needs no
   // vote on its seeds, 2 - Z seeds the reciprocal of Z and 1 - (n - 1) that of n (dm_div3_seeded, dm_div_seeded).
   int32_t flags;
   int32_t cubic; // 1: a knot interval of a Spline temperature function
-  // ---- the rest: the fall-back vote, the layer search, Spline segments ----
+  // ---- the rest: the fall-back vote, the layer search, Spline segments, the host ----
   // atm_certify: the part [safe_lo, safe_hi) of the segment over which T, p, p/T, Z and n are PROVEN to stay inside the operand range of
   // the GPU's division / square-root shortcuts (detmath.h); empty (lo = +inf) when nothing can be proven.  An evaluation outside it
   // takes the IEEE operations, so a pathological atmosphere (a spline that overshoots to 30 K, a pressure of 1e308 Pa) is slower but
   // still bit-identical to the host.
   double safe_lo, safe_hi;
   double from;  // segment k >= 1 applies for h >= from
+  double pb;    // pressure at hb
+  double lapse; // c1 = dT/dh at hb
+  double expo;  // linear: lapse != 0 ? -g0 M/(R lapse) : -g0 M/(R tb);  cubic: -g0 M/R
   double c2;
   double c3;
+  double _pad[2];
 };
 constexpr int32_t ATM_SEG_ISOTHERMAL = 1, ATM_SEG_TIGHT = 2;
 struct AtmTable {
@@ -97,7 +99,7 @@ struct AtmTable {
   ATMRT_HD const AtmSeg& seg(int k) const { return reinterpret_cast<const AtmSeg*>(this + 1)[k]; }
   ATMRT_HD AtmSeg& seg(int k) { return reinterpret_cast<AtmSeg*>(this + 1)[k]; }
 };
-static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 128 && offsetof(AtmSeg, exp_thr) == 64, "device and host read the table as header + records");
+static_assert(sizeof(AtmTable) == 32 && sizeof(AtmSeg) == 160 && offsetof(AtmSeg, k_refr) == 64, "device and host read the table as header + records");
 // the table in the constant address space (it is read-only for a whole launch): wave-uniform indices become scalar loads
 #if defined(__HIPCC__)
 typedef const __attribute__((address_space(4))) AtmTable* AtmConstTable;
@@ -331,6 +333,10 @@ inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTabl
     double pk = out.seg(k + 1).pb * atm_pressure_ratio(out, k + 1, out.seg(k + 1).from); // p at the boundary, from above
     out.seg(k).pb = pk / atm_pressure_ratio(out, k, out.seg(k + 1).from);
   }
+  for (int k = 0; k < n; k++) { // the density form of n(h) on Linear segments (oracle/atmosphere.c oracle_n)
+    out.seg(k).ptb = out.seg(k).pb / out.seg(k).tb;
+    out.seg(k).expo1 = out.seg(k).lapse != 0.0 ? out.seg(k).expo - 1.0 : out.seg(k).expo;
+  }
   {
     const double k0 = 238.0185, k1 = 5792105.0, k2 = 57.362, k3 = 167917.0;
     const double xco2 = 450.0, pr1 = 101325.0, tr1 = 288.15, za = 0.9995922115, r = 8.314472;
@@ -397,7 +403,8 @@ inline bool atm_interval_certified(const AtmTable& t, int k, double lo, double h
     tmax = t0 < t1 ? t1 : t0;
     if (!(tmin >= 1.0 && tmax <= 1.0e5)) return false;
     // p / pb = exp(e) with e = expo * log(T / tb) (or expo * (h - hb) on an isothermal segment): monotone in h, so the end points
-    // bound it.  Within 1e-280 .. 1e280 means |e| <= 645 < 700 at every point of the interval: the certified evaluation may call
+    // bound it.  Within 1e-280 .. 1e280 means |e| <= 645 at every point of the interval, and the exponent the kernels form, that of
+    // p / T = ptb x^(expo - 1), differs from e by log x, |log x| <= 11.6: at most 657 < 700 — the certified evaluation may call
     // the main branch of exp without asking (refr_n_layer3) — and x = fma(gtb, h - hb, 1), monotone in h and with T = tb x in 1 .. 1e5 K
     // at both ends, is a positive normal number (>= 1e-5 (1 - 2^-52)): the main branch of log likewise.
     const double r0 = atm_pressure_ratio(t, k, lo), r1 = atm_pressure_ratio(t, k, hi);
@@ -469,9 +476,9 @@ inline void atm_certify(AtmTable& t, bool spherical, double radius, double step)
     t.seg(k).safe_hi = t.seg(k).tight_hi = -dm_inf();
     t.seg(k).flags = !t.seg(k).cubic && t.seg(k).lapse == 0.0 ? ATM_SEG_ISOTHERMAL : 0;
     t.seg(k).k_refr = t.k_refr;
-    // the exponents of the three points of one right-hand side: e = expo log(T / tb), log arguments within 2^-21 of one another on
-    // a tight segment (+ the rounding of log itself: 4 ulp of a value below 12), or e = expo (h - hb) with h 1 cm apart
-    const double ae = dm_fabs(t.seg(k).expo);
+    // the exponents of the three points of one right-hand side: e = expo1 log(x), log arguments within 2^-21 of one another on
+    // a tight segment (+ the rounding of log itself: 4 ulp of a value below 12), or e = expo1 (h - hb) with h 1 cm apart
+    const double ae = dm_fabs(t.seg(k).expo1);
     const double de = t.seg(k).lapse != 0.0 ? ae * (4.76837158203125e-07 + 1.0e-14) : ae * 0.01 * (1.0 + 1.0e-9);
     const double margin = 1.01 * de * DM_INVLN2N + 1.0e-6;
     t.seg(k).exp_thr = margin < 0.5 ? 0.5 - margin : -1.0; // (NaN: -1)
@@ -585,22 +592,21 @@ ATMRT_HD double ciddor_z(double pt, double t) {
   const double na = DM_FMA_VVS(t, DM_FMA_VSV(t, -a2, -a1), -a0);
   return DM_FMA(pt, DM_FMA_VSV(pt, d, na), 1.0);
 }
-// Ciddor's (n - 1) = K (p/T) / Z for dry air
+// Ciddor's (n - 1) = K (p/T) / Z for dry air, from the density term pt = p / T and t = T - 273.15
 template <bool FAST = false>
-ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) {
-  double t = temp - 273.15;
-  double pt = div_sel<FAST>(p, temp);
-  double z = ciddor_z(pt, t);
-  return 1.0 + div_sel<FAST>(k_refr * pt, z);
+ATMRT_HD double refr_from_pt(double k_refr, double pt, double t) {
+  return 1.0 + div_sel<FAST>(k_refr * pt, ciddor_z(pt, t));
+}
+template <bool FAST = false>
+ATMRT_HD double refr_from_tp(double k_refr, double temp, double p) { // Spline segments: p and T come separately
+  return refr_from_pt<FAST>(k_refr, div_sel<FAST>(p, temp), temp - 273.15);
 }
 
-// refr_from_tp at the three points of one ODE right-hand side (same layer, heights 1 cm apart): the same values as three calls; the
-// two division sites share their reciprocal refinement across the points (dm_div3)
-ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, double p0, double p1, double p2, double& n0, double& n1,
+// refr_from_pt at the three points of one ODE right-hand side (same layer, heights 1 cm apart): the same values as three calls; the
+// division site shares its reciprocal refinement across the points (dm_div3)
+ATMRT_HD void refr_from_pt3(double k_refr, double pt0, double pt1, double pt2, double t0, double t1, double t2, double& n0, double& n1,
                             double& n2) {
-  double pt0, pt1, pt2;
-  dm_div3(p0, t0, p1, t1, p2, t2, &pt0, &pt1, &pt2);
-  const double z0 = ciddor_z(pt0, t0 - 273.15), z1 = ciddor_z(pt1, t1 - 273.15), z2 = ciddor_z(pt2, t2 - 273.15);
+  const double z0 = ciddor_z(pt0, t0), z1 = ciddor_z(pt1, t1), z2 = ciddor_z(pt2, t2);
   double q0, q1, q2;
   dm_div3(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, &q0, &q1, &q2);
   n0 = 1.0 + q0;
@@ -608,12 +614,10 @@ ATMRT_HD void refr_from_tp3(double k_refr, double t0, double t1, double t2, doub
   n2 = 1.0 + q2;
 }
 
-// the same on a TIGHT segment (AtmSeg::flags): no votes, the reciprocal of Z seeded by 2 - Z; q0 = n0 - 1 seeds the caller's 1 / n0
-ATMRT_HD void refr_from_tp3_tight(double k_refr, double t0, double t1, double t2, double p0, double p1, double p2, double& n0, double& n1,
+// the same on a TIGHT segment (AtmSeg::flags): no vote, the reciprocal of Z seeded by 2 - Z; q0 = n0 - 1 seeds the caller's 1 / n0
+ATMRT_HD void refr_from_pt3_tight(double k_refr, double pt0, double pt1, double pt2, double t0, double t1, double t2, double& n0, double& n1,
                                   double& n2, double& q0) {
-  double pt0, pt1, pt2;
-  dm_div3_seeded(p0, t0, p1, t1, p2, t2, 0, 0.0, &pt0, &pt1, &pt2);
-  const double z0 = ciddor_z(pt0, t0 - 273.15), z1 = ciddor_z(pt1, t1 - 273.15), z2 = ciddor_z(pt2, t2 - 273.15);
+  const double z0 = ciddor_z(pt0, t0), z1 = ciddor_z(pt1, t1), z2 = ciddor_z(pt2, t2);
   double q1, q2;
   dm_div3_seeded(k_refr * pt0, z0, k_refr * pt1, z1, k_refr * pt2, z2, 1, 2.0 - z0, &q0, &q1, &q2);
   n0 = 1.0 + q0;
@@ -633,13 +637,12 @@ ATMRT_HD double refr_n_cubic_segment(double k_refr, double hb, double tb, double
 // closed-form path of Linear functions: the stepping kernels are compiled in both variants and the host picks by
 // whether the atmosphere has Spline segments (inlining the quadrature path twelve times per RK4 step costs 9 % on US-76).
 template <bool CUBIC = true, bool FAST = false>
-ATMRT_HD double refr_n_layer(double k_refr, int cubic, double hb, double tb, double gtb, double pb, double lapse, double c2, double c3,
-                             double expo, double h) {
-  if (CUBIC && cubic) return refr_n_cubic_segment<FAST>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h);
-  double x = DM_FMA(gtb, h - hb, 1.0);
-  double temp = tb * x;
-  double ratio = lapse != 0.0 ? dm_pow(x, expo) : dm_exp(expo * (h - hb));
-  return refr_from_tp<FAST>(k_refr, temp, pb * ratio);
+ATMRT_HD double refr_n_layer(double k_refr, const AtmSeg& sg, double h) {
+  if (CUBIC && sg.cubic) return refr_n_cubic_segment<FAST>(k_refr, sg.hb, sg.tb, sg.pb, sg.lapse, sg.c2, sg.c3, sg.expo, h);
+  const double dh = h - sg.hb;
+  const double x = DM_FMA(sg.gtb, dh, 1.0);
+  const double pt = sg.lapse != 0.0 ? sg.ptb * dm_pow(x, sg.expo1) : sg.ptb * dm_exp(sg.expo1 * dh);
+  return refr_from_pt<FAST>(k_refr, pt, DM_FMA(sg.tb, x, -273.15));
 }
 
 // refr_n_layer at three points of one layer.  Same values as three calls; on the GPU the range guards of log and exp are
@@ -718,40 +721,40 @@ ATMRT_HD void exp3_tight(double e0, double e1, double e2, double thr, double& r0
 // normal number and |expo log(T / tb)| (|expo (h - hb)| on an isothermal segment) is at most 645, so log and exp take their main
 // branches unasked — the values of refr_n_layer at the three points.
 template <bool CUBIC = true>
-ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr, double hb, double tb, double gtb, double pb, double lapse,
-                            double c2, double c3, double expo, double h0, double h1, double h2, double& n0, double& n1, double& n2, double& q0) {
+ATMRT_HD void refr_n_layer3(double k_refr, int cubic, int flags, double exp_thr, double hb, double tb, double gtb, double ptb, double expo1,
+                            double pb, double lapse, double c2, double c3, double expo, double h0, double h1, double h2, double& n0,
+                            double& n1, double& n2, double& q0) {
   if (CUBIC && cubic) {
     n0 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h0);
     n1 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h1);
     n2 = refr_n_cubic_segment<true>(k_refr, hb, tb, pb, lapse, c2, c3, expo, h2);
     return;
   }
-  (void)lapse;
   const double d0 = h0 - hb, d1 = h1 - hb, d2 = h2 - hb;
   const double x0 = DM_FMA(gtb, d0, 1.0), x1 = DM_FMA(gtb, d1, 1.0), x2 = DM_FMA(gtb, d2, 1.0);
-  const double t0 = tb * x0, t1 = tb * x1, t2 = tb * x2;
+  const double t0 = DM_FMA(tb, x0, -273.15), t1 = DM_FMA(tb, x1, -273.15), t2 = DM_FMA(tb, x2, -273.15);
   double r0, r1, r2;
   if (flags & ATM_SEG_TIGHT) {
-    if (!(flags & ATM_SEG_ISOTHERMAL)) pow3_tight(x0, x1, x2, expo, exp_thr, r0, r1, r2);
-    else exp3_tight(expo * d0, expo * d1, expo * d2, exp_thr, r0, r1, r2);
-    refr_from_tp3_tight(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2, q0);
+    if (!(flags & ATM_SEG_ISOTHERMAL)) pow3_tight(x0, x1, x2, expo1, exp_thr, r0, r1, r2);
+    else exp3_tight(expo1 * d0, expo1 * d1, expo1 * d2, exp_thr, r0, r1, r2);
+    refr_from_pt3_tight(k_refr, ptb * r0, ptb * r1, ptb * r2, t0, t1, t2, n0, n1, n2, q0);
     return;
   }
   if (!(flags & ATM_SEG_ISOTHERMAL)) {
-    pow3_in_range(x0, x1, x2, expo, r0, r1, r2);
+    pow3_in_range(x0, x1, x2, expo1, r0, r1, r2);
   } else {
-    r0 = dm_exp_main(expo * d0);
-    r1 = dm_exp_main(expo * d1);
-    r2 = dm_exp_main(expo * d2);
+    r0 = dm_exp_main(expo1 * d0);
+    r1 = dm_exp_main(expo1 * d1);
+    r2 = dm_exp_main(expo1 * d2);
   }
-  refr_from_tp3(k_refr, t0, t1, t2, pb * r0, pb * r1, pb * r2, n0, n1, n2);
+  refr_from_pt3(k_refr, ptb * r0, ptb * r1, ptb * r2, t0, t1, t2, n0, n1, n2);
 }
 
 // Environment::n(h) (renderer/mod.rs:425 is the only direct call site; the stepper uses it too).  IEEE operations throughout: the
 // generic evaluation, valid for any atmosphere at any altitude.
 ATMRT_HD double refr_n(const AtmTable& a, double h) {
   int k = atm_layer(a, h);
-  return refr_n_layer(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+  return refr_n_layer(a.k_refr, a.seg(k), h);
 }
 ATMRT_HD double refr_dn(const AtmTable& a, double h) {
   const double eps = 0.01;
@@ -765,17 +768,17 @@ ATMRT_HD double refr_dn(const AtmTable& a, double h) {
 // Straight-line code.  For a point outside, the result is garbage of no consequence (every table index is masked): callers
 // discard it (refr_n_speculative's `certified` flag).
 template <bool CUBIC>
-ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double tb, double gtb, double pb, double lapse, double c2, double c3,
-                                     double expo, double h) {
+ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double tb, double gtb, double ptb, double expo1, double pb,
+                                     double lapse, double c2, double c3, double expo, double h) {
   if (CUBIC && cubic) {
     const double temp = seg_temperature(tb, lapse, c2, c3, h - hb);
     const double p = pb * dm_exp_main(expo * seg_inv_t_integral(tb, lapse, c2, c3, h - hb));
     return refr_from_tp<true>(k_refr, temp, p);
   }
-  const double x = DM_FMA(gtb, h - hb, 1.0);
-  const double temp = tb * x;
-  const double e = lapse != 0.0 ? expo * dm_log_core_pow(x) : expo * (h - hb);
-  return refr_from_tp<true>(k_refr, temp, pb * dm_exp_main(e));
+  const double dh = h - hb;
+  const double x = DM_FMA(gtb, dh, 1.0);
+  const double e = lapse != 0.0 ? expo1 * dm_log_core_pow(x) : expo1 * dh;
+  return refr_from_pt<true>(k_refr, ptb * dm_exp_main(e), DM_FMA(tb, x, -273.15));
 }
 
 // One evaluation of n(h) with the shortcut divisions, organised for the wavefront of the path kernel (atmrt_paths.hip): `hint` is the
@@ -790,7 +793,7 @@ ATMRT_HD double refr_n_layer_inrange(double k_refr, int cubic, double hb, double
 struct AtmLayerCache {
   int k = -1;
   int cubic = 0;
-  double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, gtb = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
+  double safe_lo = 0.0, safe_hi = 0.0, hb = 0.0, tb = 0.0, gtb = 0.0, ptb = 0.0, expo1 = 0.0, pb = 0.0, lapse = 0.0, c2 = 0.0, c3 = 0.0, expo = 0.0, k_refr = 0.0;
 };
 template <bool CUBIC>
 __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayerCache& cache, double h, int& hint, bool& certified) {
@@ -799,19 +802,19 @@ __device__ __forceinline__ double refr_n_speculative(const AtmTable& a, AtmLayer
     const AtmConstSeg ks = atm_const_seg(a, ku);
     cache.k = ku;
     cache.cubic = ks->cubic;
-    cache.safe_lo = ks->safe_lo, cache.safe_hi = ks->safe_hi, cache.hb = ks->hb, cache.tb = ks->tb, cache.gtb = ks->gtb, cache.pb = ks->pb;
+    cache.safe_lo = ks->safe_lo, cache.safe_hi = ks->safe_hi, cache.hb = ks->hb, cache.tb = ks->tb, cache.gtb = ks->gtb, cache.ptb = ks->ptb, cache.expo1 = ks->expo1, cache.pb = ks->pb;
     cache.lapse = ks->lapse, cache.c2 = ks->c2, cache.c3 = ks->c3, cache.expo = ks->expo;
     cache.k_refr = atm_const_table(a)->k_refr;
   }
   if (__all(h >= cache.safe_lo && h < cache.safe_hi)) {
     certified = true;
-    return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.gtb, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
+    return refr_n_layer_inrange<CUBIC>(cache.k_refr, cache.cubic, cache.hb, cache.tb, cache.gtb, cache.ptb, cache.expo1, cache.pb, cache.lapse, cache.c2, cache.c3, cache.expo, h);
   }
   const int k = atm_layer(a, h);
   hint = k;
   const AtmSeg& sg = a.seg(k);
   certified = h >= sg.safe_lo && h < sg.safe_hi;
-  return refr_n_layer_inrange<CUBIC>(a.k_refr, sg.cubic, sg.hb, sg.tb, sg.gtb, sg.pb, sg.lapse, sg.c2, sg.c3, sg.expo, h);
+  return refr_n_layer_inrange<CUBIC>(a.k_refr, sg.cubic, sg.hb, sg.tb, sg.gtb, sg.ptb, sg.expo1, sg.pb, sg.lapse, sg.c2, sg.c3, sg.expo, h);
 }
 #endif
 
@@ -829,11 +832,11 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   const AtmConstSeg ks = atm_const_seg(a, ku);
   const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi);
   if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi)) {
-    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, gtb = ks->gtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, gtb = ks->gtb, ptb = ks->ptb, expo1 = ks->expo1, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n1, n2, q0;
-    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, gtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, gtb, ptb, expo1, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
     dn = (n2 - n1) * REFR_INV_2EPS;
     return true;
   }
@@ -842,10 +845,10 @@ ATMRT_HD bool refr_n_dn_hint(const AtmTable& a, double h, int& hint, double& n, 
   {
     const int k = atm_layer(a, h);
     hint = k;
-    n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+    n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k), h);
     const int k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
-    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).gtb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
-    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).gtb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
+    const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1), h1);
+    const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2), h2);
     dn = (n2 - n1) * REFR_INV_2EPS;
     return false;
   }
@@ -1222,9 +1225,9 @@ ATMRT_HD double ray_accel_generic(const AtmTable& a, bool spherical, double radi
   const double h = spherical ? pa - radius : pa, h1 = h - eps, h2 = h + eps;
   const int k = atm_layer(a, h), k1 = atm_layer(a, h1), k2 = atm_layer(a, h2);
   hint = k; // the hint follows the lane, so that the fast path resumes once the wavefront is back inside one certified interval
-  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
-  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1).cubic, a.seg(k1).hb, a.seg(k1).tb, a.seg(k1).gtb, a.seg(k1).pb, a.seg(k1).lapse, a.seg(k1).c2, a.seg(k1).c3, a.seg(k1).expo, h1);
-  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2).cubic, a.seg(k2).hb, a.seg(k2).tb, a.seg(k2).gtb, a.seg(k2).pb, a.seg(k2).lapse, a.seg(k2).c2, a.seg(k2).c3, a.seg(k2).expo, h2);
+  const double n = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k), h);
+  const double n1 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k1), h1);
+  const double n2 = refr_n_layer<CUBIC, false>(a.k_refr, a.seg(k2), h2);
   const double dn = (n2 - n1) * REFR_INV_2EPS;
   return accel_rhs<false>(spherical, pa, pb, n, dn);
 }
@@ -1247,11 +1250,11 @@ ATMRT_HD double ray_accel(const AtmTable& atm, bool spherical, double radius, do
   const bool slope_ok = !(dm_fabs(b) > ACCEL_FAST_MAX_B);
   const bool tight = __all(h1 >= ks->tight_lo && h2 < ks->tight_hi && slope_ok);
   if (tight || __all(h1 >= ks->safe_lo && h2 < ks->safe_hi && slope_ok)) {
-    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, gtb = ks->gtb, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
+    const double k_refr = ks->k_refr, hb = ks->hb, tb = ks->tb, gtb = ks->gtb, ptb = ks->ptb, expo1 = ks->expo1, pb = ks->pb, lapse = ks->lapse, c2 = ks->c2, c3 = ks->c3, expo = ks->expo;
     const int cubic = ks->cubic, flags = tight ? ks->flags : ks->flags & ~ATM_SEG_TIGHT;
     const double exp_thr = ks->exp_thr;
     double n, n1, n2, q0;
-    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, gtb, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
+    refr_n_layer3<CUBIC>(k_refr, cubic, flags, exp_thr, hb, tb, gtb, ptb, expo1, pb, lapse, c2, c3, expo, h, h1, h2, n, n1, n2, q0);
     const double dn = (n2 - n1) * REFR_INV_2EPS;
     fast = true;
     if ((flags & ATM_SEG_TIGHT) && !(CUBIC && cubic)) return accel_rhs_tight(spherical, a, b, n, q0, dn);

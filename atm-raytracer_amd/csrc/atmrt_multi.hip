@@ -192,7 +192,9 @@ struct MultiGroup {
   std::string demoted;  // why the context left the RCCL route for peer copies (empty: it did not)
   bool aborted = false; // a device failed inside a task that has barriers: the others stop waiting (guarded by bm)
 
-  // All devices meet here; false: one of them failed since the task began, and nobody waits any more.
+  // All devices meet here; false: one of them failed before they all had arrived, and nobody waits any more.  A barrier that
+  // COMPLETED stays completed: a device that fails right after leaving it (its own arguments were wrong: tile_hits reports that
+  // after the collective) sets `aborted` while its peers may not yet have woken up from the same barrier — they must go on.
   bool barrier() {
     std::unique_lock<std::mutex> lk(bm);
     if (aborted) return false;
@@ -201,10 +203,10 @@ struct MultiGroup {
       bcount = 0;
       bgen++;
       bcv.notify_all();
-    } else {
-      bcv.wait(lk, [&] { return bgen != gen || aborted; });
+      return true;
     }
-    return !aborted;
+    bcv.wait(lk, [&] { return bgen != gen || aborted; });
+    return bgen != gen;
   }
   void abort_task() {
     std::lock_guard<std::mutex> lk(bm);

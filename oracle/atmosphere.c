@@ -18,7 +18,8 @@
  * fix; they are fixed HERE, and the product follows bit for bit.  Where the published formula has the shape a*b + c it is one fused
  * multiply-add (C99 fma, exactly rounded in either flavour):
  *     dh = h - hb;  x = T / tb = fma(lapse / tb, dh, 1);  T = tb x  (the barometric formula's own variable, p = pb x^expo);
- *     Z = fma(pt, fma(pt, d, -A), 1),  A = fma(t, fma(t, a2, a1), a0),  pt = p / T,  t = T - 273.15;   n = 1 + k pt / Z.
+ *     n(h) on a Linear segment takes the density term directly, pt = p / T = (pb / tb) x^(expo - 1), and t = fma(tb, x, -273.15);
+ *     Z = fma(pt, fma(pt, d, -A), 1),  A = fma(t, fma(t, a2, a1), a0);   n = 1 + k pt / Z.
  * Against the round-3 order (every operation rounded separately, T / tb by division) the outputs of a frame move by rounding
  * errors only: tests/test_oracle.py::test_fused_evaluation_order_moves_results_by_rounding_only holds the measured bound.
  */
@@ -291,14 +292,24 @@ double oracle_atm_pressure(const oracle_env_atm* a, double h) {
 
 /* Environment::n(h) */
 double oracle_n(const oracle_env_atm* a, double h) {
-  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
   int k = layer_of(a, h);
-  double temp = seg_temperature(a, k, h);
-  double p = a->pb[k] * pressure_ratio(a, k, h);
-  double t = temp - 273.15;
-  double pt = p / temp;
-  double aa = om_fma(t, om_fma(t, a2, a1), a0);
-  double z = om_fma(pt, om_fma(pt, d, -aa), 1.0); /* 1 - pt (a0 + a1 t + a2 t^2) + pt^2 d */
+  double pt, t, aa, z;
+  const double a0 = 1.58123e-6, a1 = -2.9331e-8, a2 = 1.1043e-10, d = 1.83e-11;
+  if (a->cubic[k]) {
+    double temp = seg_temperature(a, k, h);
+    pt = a->pb[k] * pressure_ratio(a, k, h) / temp;
+    t = temp - 273.15;
+  } else {
+    /* Linear segment: Ciddor needs the air density, i.e. p / T, and on a Linear segment that is itself a closed form,
+     * p / T = (pb / tb) x^(expo - 1) with x = T / tb  (isothermal: (pb / tb) exp(expo dh)) — no division per evaluation */
+    double dh = h - a->hb[k];
+    double x = om_fma(a->lapse[k] / a->tb[k], dh, 1.0);
+    double ptb = a->pb[k] / a->tb[k];
+    pt = a->lapse[k] != 0.0 ? ptb * om_pow(x, a->expo[k] - 1.0) : ptb * om_exp(a->expo[k] * dh);
+    t = om_fma(a->tb[k], x, -273.15);
+  }
+  aa = om_fma(t, om_fma(t, a2, a1), a0);
+  z = om_fma(pt, om_fma(pt, d, -aa), 1.0); /* 1 - pt (a0 + a1 t + a2 t^2) + pt^2 d */
   return 1.0 + a->k_refr * pt / z;
 }
 

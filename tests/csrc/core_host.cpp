@@ -57,7 +57,7 @@ int ch_certify(const atmrt_atmosphere_t* def, double wavelength, int spherical, 
       double h = a.seg(k).safe_lo + (a.seg(k).safe_hi - a.seg(k).safe_lo) * i / N;
       double t = atm_seg_temperature(a, k, h), pr = a.seg(k).pb * atm_pressure_ratio(a, k, h), pt = pr / t, c = t - 273.15;
       double z = 1.0 - pt * (1.58123e-6 + c * (-2.9331e-8 + c * 1.1043e-10)) + pt * pt * 1.83e-11;
-      double n = refr_n_layer(a.k_refr, a.seg(k).cubic, a.seg(k).hb, a.seg(k).tb, a.seg(k).gtb, a.seg(k).pb, a.seg(k).lapse, a.seg(k).c2, a.seg(k).c3, a.seg(k).expo, h);
+      double n = refr_n_layer(a.k_refr, a.seg(k), h);
       if (!(t >= min_t[k])) min_t[k] = t;
       if (!(pt <= max_pt[k])) max_pt[k] = pt;
       double zd = z > 1.0 ? z - 1.0 : 1.0 - z;

@@ -21,7 +21,9 @@
  *     n(h) on a Linear segment takes the density term directly, pt = p / T = (pb / tb) x^(expo - 1), and t = fma(tb, x, -273.15);
  *     Z = fma(pt, fma(pt, d, -A), 1),  A = fma(t, fma(t, a2, a1), a0);   n = 1 + k pt / Z.
  * Against the round-3 order (every operation rounded separately, T / tb by division) the outputs of a frame move by rounding
- * errors only: tests/test_oracle.py::test_fused_evaluation_order_moves_results_by_rounding_only holds the measured bound.
+ * errors only: tests/test_oracle_known_answers.py compares both with the modular forms (n from pressure(h) / temperature(h); the two-term right-hand
+ * side and textbook RK4 sums) in multi-precision arithmetic, and the golden vectors written under the round-3 order are still
+ * reproduced to 1e-9 (tests/test_golden.py: deliberately not regenerated).
  */
 #include "oracle.h"
 #include "oracle_math.h"

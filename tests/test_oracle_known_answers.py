@@ -194,3 +194,69 @@ def test_multi_hit_terrain_alpha(oracle):
     for p in np.argwhere(r["hit_count"] > 1)[:50]:
         o, c = int(r["hit_offset"][tuple(p)]), int(r["hit_count"][tuple(p)])
         assert np.all(np.diff(r["distance"][o:o + c]) > 0)
+
+
+def _ciddor_n_minus_1(k_refr, p, t_kelvin):
+    """(n - 1) = k (p/T) / Z in 50-digit arithmetic, Z as NIST's toolbox documents it for dry air."""
+    a0, a1, a2, d = (mpmath.mpf(v) for v in ("1.58123e-6", "-2.9331e-8", "1.1043e-10", "1.83e-11"))
+    pt = mpmath.mpf(p) / mpmath.mpf(t_kelvin)
+    t = mpmath.mpf(t_kelvin) - mpmath.mpf("273.15")
+    z = 1 - pt * (a0 + a1 * t + a2 * t * t) + pt * pt * d
+    return mpmath.mpf(k_refr) * pt / z
+
+
+def test_density_form_of_n_equals_pressure_over_temperature(oracle):
+    """oracle_n evaluates Ciddor's density term on a Linear segment as (pb / tb) x^(expo - 1), x = T / tb, in fused multiply-adds
+    (oracle/atmosphere.c: the evaluation order is this build's to fix, the crate being absent).  That must be the modular form —
+    n from the atmosphere's own pressure(h) and temperature(h) — to rounding: both sides are compared in 50-digit arithmetic over every
+    layer of US-76, isothermal ones included, and over a custom atmosphere with a steep inversion."""
+    custom = config._atmosphere({"pressure": {"altitude": 120.0, "pressure": 99_800.0},
+                                 "temperature_fixed_point": {"altitude": 0.0, "temperature": 275.0},
+                                 "first_temperature_function": {"Linear": {"gradient": 0.11}},
+                                 "next_functions": [{"altitude": 150.0, "function": {"Linear": {"gradient": -0.0098}}},
+                                                    {"altitude": 9000.0, "function": {"Linear": {"gradient": 0.0}}}]})
+    mpmath.mp.dps = 50
+    worst = 0.0
+    for atm in (None, custom):
+        env = oracle.env(atm)
+        for h in np.concatenate([np.linspace(-900.0, 12_000.0, 259), np.linspace(12_000.0, 84_000.0, 145)]):
+            want = _ciddor_n_minus_1(env.k_refr, oracle.pressure(env, float(h)), oracle.temperature(env, float(h)))
+            got = mpmath.mpf(oracle.n(env, float(h))) - 1
+            # n = 1 + q carries the rounding of the sum: half an ulp of 1 against q ~ 3e-4 .. 1e-8
+            assert abs(got - want) <= mpmath.mpf(2) ** -52 + abs(want) * mpmath.mpf("1e-13"), (h, got, want)
+            worst = max(worst, float(abs(got - want)))
+    assert worst <= 2.3e-16
+
+
+def test_stepper_single_denominator_equals_the_two_term_right_hand_side(oracle):
+    """oracle/stepper.c takes the spherical right-hand side over one denominator and forms the RK4 stage points and sums with fused
+    multiply-adds.  Integrated again in 40-digit arithmetic with the TEXTBOOK forms — r'' = r + 2 r'^2 / r + (r^2 + r'^2) n' / n,
+    y + h/6 (k1 + 2 k2 + 2 k3 + k4) — from the oracle's own n(h) and dn/dh(h), a 100 km ray must come out where the oracle puts it
+    to micrometres (measured: 0.6 um after 1000 steps; what is left is the rounding of the oracle's own f64 arithmetic at r = 6.4e6 m,
+    one ulp of which is 0.9 nm, and the 1 cm difference quotient's sensitivity to where it is evaluated)."""
+    mpmath.mp.dps = 40
+    env = oracle.env()
+    cfg, _ = synth.scene("S2", 8, 8)
+    step, n_steps, h0 = 100.0, 1000, 1500.0
+    for ang_deg in (-0.4, 0.3):
+        _, h = oracle.ray_paths(cfg.params, h0, [ang_deg], step, n_steps)
+        radius = mpmath.mpf(R)
+        a, b = mpmath.mpf(h0) + radius, (mpmath.mpf(h0) + radius) * mpmath.tan(mpmath.radians(mpmath.mpf(ang_deg)))
+        d = mpmath.mpf(step) / radius
+
+        def acc(r, v):
+            hh = float(r - radius)
+            n, dn = mpmath.mpf(oracle.n(env, hh)), mpmath.mpf(oracle.dn(env, hh))
+            return r + 2 * v * v / r + (r * r + v * v) * dn / n
+
+        for i in range(1, n_steps + 1):
+            k1a, k1b = b, acc(a, b)
+            k2a = b + d / 2 * k1b
+            k2b = acc(a + d / 2 * k1a, k2a)
+            k3a = b + d / 2 * k2b
+            k3b = acc(a + d / 2 * k2a, k3a)
+            k4a = b + d * k3b
+            k4b = acc(a + d * k3a, k4a)
+            a, b = a + d / 6 * (k1a + 2 * k2a + 2 * k3a + k4a), b + d / 6 * (k1b + 2 * k2b + 2 * k3b + k4b)
+            if i % 250 == 0:
+                assert abs(float(a - radius) - h[0, i]) < 5e-6, (ang_deg, i, float(a - radius), h[0, i])

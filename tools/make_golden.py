@@ -3,6 +3,12 @@
 
 The reference cannot be run here (Rust, no toolchain) and ships no fixtures, so the vectors come from the
 oracle's glibc-libm flavour — the flavour that shares no numerics with the product.  Re-run:  python tools/make_golden.py
+
+The committed vectors were written in round 3, when the oracle rounded every operation of the absent crate's formulas separately.
+Round 4 fixed that evaluation order anew (fused multiply-adds, the density form of n(h): oracle/atmosphere.c, oracle/stepper.c) and
+the vectors were deliberately NOT regenerated: both flavours of today's oracle and the GPU reproduce them to 1e-9 with identical
+hit / miss decisions and step counts (tests/test_golden.py), which is the evidence that the new order moves results by rounding
+errors only.  Re-running this script rewrites them under the current order.
 """
 import json
 import os

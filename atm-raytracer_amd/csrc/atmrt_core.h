@@ -270,7 +270,7 @@ inline int atm_compile(const atmrt_atmosphere_t& def, double wavelength, AtmTabl
     if (!has_hi || hi > x[np - 1]) {
       double hh = x[np - 1] - x[np - 2];
       owner[n] = j;
-      out.seg(n).from = x[np - 1];
+      out.seg(n).from = (has_lo && lo > x[np - 1]) ? lo : x[np - 1]; // every knot below the function's own start: it still begins at `lo`
       out.seg(n).hb = x[np - 1];
       out.seg(n).tb = y[np - 1];
       out.seg(n).lapse = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0; // S'(x_last)

@@ -212,7 +212,7 @@ int oracle_atm_compile(const atmrt_atmosphere_t* def, double wavelength, oracle_
       }
       if (!has_hi || hi > x[np - 1]) { /* linear continuation above the last knot, slope S'(x_last) */
         double hh = x[np - 1] - x[np - 2];
-        out->from[n] = x[np - 1];
+        out->from[n] = (has_lo && lo > x[np - 1]) ? lo : x[np - 1]; /* every knot below the function's own start: it still begins at `lo` */
         out->hb[n] = x[np - 1];
         out->tb[n] = y[np - 1];
         out->lapse[n] = (y[np - 1] - y[np - 2]) / hh + hh * (m[np - 2] + 2.0 * m[np - 1]) / 6.0;

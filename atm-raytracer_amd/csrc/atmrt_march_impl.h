@@ -35,10 +35,13 @@ namespace atmrt {
 // finite-difference terrain lookups per sample and the interpolation.  Keeping the hit epilogue out
 // of the march keeps the RK4 loop at ~135 VGPRs without scratch.
 
-// 4 waves per SIMD (<= 128 VGPRs, 116 B/lane of spilled loop state): headline frame 402 ms (3 waves, no spills) / 366 ms (4) /
-// 419 ms (5) with the current n(h) code; the first version of the kernel: 790 ms (3) / 702 ms (4)
+// Wavefronts per SIMD.  Rounds 1-3 ran 4 (<= 128 VGPRs, no scratch): the loop then was saturated by its own issue slots (VALU 99.7 %
+// busy) and a fifth wavefront bought 1.5 % for 40 x the algorithmic stores in scratch traffic.  With round 4's evaluation order
+//  a ray-step is 752 lane-instructions instead of 1,154 and the four wavefronts also wait on their own dependency
+// chains (busy 91.7 %): 5 per SIMD (96 VGPRs, 116 B/lane of scratch for state that is touched once per ray) measure 173.3 against
+// 179.3 ms for the headline frame, 6 per SIMD (80 VGPRs) 175.9.  History: 402 ms (3 waves) / 366 (4) / 419 (5) in round 1.
 #ifndef ATMRT_MARCH_WAVES
-#define ATMRT_MARCH_WAVES 4
+#define ATMRT_MARCH_WAVES 5
 #endif
 // Scenes with objects (MODE 3).  The general tracer pays for its generality at every step (candidate lists, step lists,
 // collision geometry: 3 waves per SIMD), yet a step can only involve an object while the ray is inside the distance interval of a
@@ -82,8 +85,7 @@ constexpr int DRAIN_PRIO_BAND = 512;
 // The DRAIN variant also runs 5 wavefronts per SIMD (96 VGPRs, 136 B of scratch per lane) instead of 4 (127 VGPRs, none): a shard's
 // long wavefronts are 1.37 resident sets of 4096 but 1.09 sets of 5120, so far fewer of them are left to run on half-empty SIMDs at
 // the end (mean occupancy of a shard launch at 8 GPUs 0.83, VALU busy 0.86 with 4 per SIMD): 8 x 39.3 -> 8 x 36.2 ms, 4 x 73.5 ->
-// 4 x 71.2.  The whole frame would gain 1.5 % from 5 per SIMD (2.3 % from 6) and pay for it with the scratch traffic round 1 had
-// (40 x its algorithmic stores): it stays at 4, without scratch.
+// 4 x 71.2.  (Round 4: the plain and the sliced march run 5 per SIMD too, ATMRT_MARCH_WAVES.)
 #ifndef ATMRT_MARCH_WAVES_SMALL
 #define ATMRT_MARCH_WAVES_SMALL 5
 #endif
@@ -508,7 +510,7 @@ struct SliceObjects {
 };
 constexpr uint32_t SLICE_EMPTY = 0xffffffffu, SLICE_EXIT = 0xfffffffeu;
 #ifndef ATMRT_SLICE_WAVES
-#define ATMRT_SLICE_WAVES 4 // per SIMD: 128 VGPRs, no scratch (5 per SIMD measured equal: the slices hide the drain the fifth wave was for)
+#define ATMRT_SLICE_WAVES 5 // per SIMD, like the plain march (round 4: 2 x 93.3 -> 90.0 ms, 4 x 47.8 -> 46.2, 8 x 24.24 -> 24.01; 6: slower)
 #endif
 
 #ifdef ATMRT_TIMELINE

@@ -352,11 +352,13 @@ def main():
                     "effective_clock_ghz": sq.get("effective_clock_ghz"),  # GRBM_GUI_ACTIVE / 8 XCDs / the kernel's mean duration under rocprofv3
                     "lane_instructions_per_ray_step_by_kind": sq.get("lane_instructions_per_ray_step_by_kind")}
             if flops:
+                kinds = sq.get("lane_instructions_per_ray_step_by_kind") or {}
+                fp64_share = sum(v for k, v in kinds.items() if k.endswith("_F64")) / ipr
                 out = {"bound": "fp64_valu", "achieved": flops * steps_per_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                        "frac": flops * steps_per_s / 1e12 / FP64_VALU_PEAK_TF, "issue_slot_frac": rate / FP64_ISSUE_PEAK, "traffic": traffic,
                        "note": "achieved = FP64 flops per ray-step (SQ_INSTS_VALU_ADD/MUL/FMA/TRANS_F64 of this build's cached rocprofv3 passes; "
                                "FMA = 2) x live ray-steps/s; issue_slot_frac = all VALU lane-instructions/s over the FP64 issue peak: the "
-                               "pipes are that full, of which 83 % FP64 arithmetic — the rest is table-index integer work, compares, moves",
+                               f"pipes are that full, of which {100.0 * fp64_share:.0f} % FP64 arithmetic — the rest is table-index integer work, compares, moves",
                        "valu": valu, "hbm": hbm}
             else:  # counters from before the instruction-mix passes existed: issue slots only, labelled as such
                 out = {"bound": "fp64_valu_issue", "achieved": rate / 1e12, "peak": FP64_ISSUE_PEAK / 1e12, "unit": "T lane-instructions/s",

@@ -1333,6 +1333,7 @@ extern "C" int atmrt_debug_march_plan(int32_t width, int32_t height, int32_t sam
   f.h = height;
   f.n_t = samples;
   f.n_objects = n_objects;
+  f.opaque = n_objects == 0; // (the plan of a frame over opaque terrain: translucent terrain is not sliced, like scenes with objects)
   SliceLayout L{};
   const bool sliced = march_slice_layout(f, L);
   out[0] = sliced ? 1 : 0;

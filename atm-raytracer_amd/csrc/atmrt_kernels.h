@@ -156,6 +156,11 @@ static inline bool march_slice_layout(const Frame& f, SliceLayout& L) {
   // take 8 x 43.8 ms sliced against 8 x 42.3 ms through the small-launch variant of k_rect_march<3> (the slices that contain object
   // steps run long and put their groups out of step) — ATMRT_MARCH_VARIANT=sliced forces it.
   if (f.n_objects != 0 && ov != 3) return false;
+  // Translucent terrain likewise (round 4, after the march went to 5 wavefronts per SIMD; tiles of the headline at alpha 0.5, sum of the
+  // tile times): 2 tiles sliced 210 ms / plain 195 / small-launch 199, 4 tiles 211 / 203 / 208, 8 tiles 224 / 235 / 218 — rays that do
+  // not stop at the terrain are of near-uniform length, which is what the slices were there to even out; the launcher picks between
+  // the plain and the small-launch variant by the size of the grid (ATMRT_LAUNCH_MARCH).
+  if (!f.opaque && ov != 3) return false;
   if (ov ? ov != 3 : (n + 255) / 256 > MARCH_SMALL_MAX_BLOCKS) return false;
   L.n_groups = (uint32_t)((n + 63) / 64);
   L.n_pad = (size_t)L.n_groups * 64;

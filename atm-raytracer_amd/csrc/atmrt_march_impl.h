@@ -64,6 +64,14 @@ constexpr uint32_t OBJECT_RAY = 0xffffffffu; // hit_count of a ray left to k_rec
 // compiled in both variants (DRAIN) and the launcher picks one by the size of its grid (ATMRT_LAUNCH_MARCH).
 constexpr unsigned DRAIN_PRIO_MAX_BLOCKS = MARCH_SMALL_MAX_BLOCKS;
 constexpr int DRAIN_PRIO_BAND = 512;
+// Since the plain march runs 5 wavefronts per SIMD too (round 4) the small-launch variant only pays where the drain is a large part
+// of the launch: measured on the tiles of the headline (profiles/r04/march_occupancy_and_slices.json), translucent terrain (MODE 1)
+// plain / small at 16384 blocks 195 / 199 ms, at 8192 203 / 208, at 4096 235 / 218; scenes with objects (MODE 3, where the variant also
+// does the object steps out of line) 251 / 258, 295 / 267, 384 / 274.
+template <int MODE>
+constexpr unsigned drain_max_blocks() {
+  return MODE == 1 ? 6144u : MODE == 3 ? 12288u : DRAIN_PRIO_MAX_BLOCKS;
+}
 #ifndef ATMRT_MARCH_BLOCK_SMALL
 #define ATMRT_MARCH_BLOCK_SMALL 256 // workgroup size of the small-launch (DRAIN) variant
 #endif
@@ -72,7 +80,7 @@ constexpr int DRAIN_PRIO_BAND = 512;
   do {                                                                                                                                 \
     const unsigned blocks_ = cdiv((size_t)(N), 256);                                                                                   \
     const int override_ = march_variant_override();                                                                                    \
-    if (override_ ? override_ != 1 : blocks_ <= DRAIN_PRIO_MAX_BLOCKS) {                                                               \
+    if (override_ ? override_ != 1 : blocks_ <= drain_max_blocks<MODE>()) {                                                            \
       ATMRT_DISPATCH_CALC(f.earth.calc, hipLaunchKernelGGL((k_rect_march<MODE, CALC, CUBIC, true>),                                    \
                                                             dim3(cdiv((size_t)(N), ATMRT_MARCH_BLOCK_SMALL)), dim3(ATMRT_MARCH_BLOCK_SMALL), 0, STREAM, \
                                                             __VA_ARGS__));                                                             \

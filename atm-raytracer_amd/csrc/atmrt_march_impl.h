@@ -1020,9 +1020,14 @@ static __device__ __attribute__((noinline)) void step_object_pred(StepHits& sh, 
   }
 }
 #endif
-// 3 waves per SIMD (168 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above)
+// 4 waves per SIMD (128 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above) — and ONLY with the VGPR allocator that
+// never splits a live range (csrc/Makefile TRACE_RA).  With the default allocator this kernel at 128 VGPRs counts wrong ray-steps
+// and azimuths in object scenes with interprocedural register allocation already OFF (round 4: full-size config 5 through 8 tiles,
+// seed 500011 of the random sweep, tools/trace_waves_probe.py), the second trigger of the failure that IPRA alone was blamed for;
+// profiles/r04/ipra/README.md has the ablations.  This loop is the pattern they point at: lanes leave it one by one (break) while
+// the others go on through out-of-line calls, around which the splitting allocator moves values from register to register.
 #ifndef ATMRT_TRACE_WAVES
-#define ATMRT_TRACE_WAVES 3
+#define ATMRT_TRACE_WAVES 4
 #endif
 template <bool FILL, int CALC, bool CUBIC>
 __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, DensePlanes out, const uint64_t* __restrict__ hit_offset,

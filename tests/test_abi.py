@@ -53,6 +53,8 @@ def test_build_info_names_the_sources_and_the_required_flags(lib):
     info = _lib.build_info()
     assert info["source_hash"] == _lib.source_hash(), "libatmrt.so was not built from this tree: run make -C atm-raytracer_amd/csrc"
     assert "-enable-ipra=0" in info["calling_units"] and "-disable-machine-licm" in info["march_units"] and info["arch"] == "gfx950"
+    # round 4 (profiles/r04/ipra/README.md): no live-range splitting around the calls of the loops that lanes leave one by one
+    assert "-vgpr-regalloc=basic" in info["trace_units"] and "-grow-region-complexity-budget=0" in info["march_units"]
     assert "-ffp-contract=off" in info["all"]
 
 

@@ -6,8 +6,8 @@ from util import run_gpu, run_oracle, bits
 from oracle_binding import Oracle
 o = Oracle("det")
 ctx = generators.Context(0)
-# seed 500011 of test_randomised_configurations and the probe scenes of tools/ipra_probe.py, each against the oracle
-import importlib.util
+# the probe scenes of tools/ipra_probe.py, each against the oracle bit for bit incl. the ray-step count (profiles/r04/ipra/README.md part 2;
+# tests/test_gpu_march_variants.py runs this file with ATMRT_MARCH_VARIANT=plain)
 for name, kw, okw in (("scene_objects", dict(terrain_alpha=1.0), dict(n_cyl=14, n_bill=6, dist=(1_000.0, 40_000.0), spread_deg=25.0)),
                       ("per_lane_list", dict(terrain_alpha=0.5, max_distance=20_000.0, tilt=-2.0), dict(n_cyl=14, n_bill=0, dist=(1_500.0, 1_650.0), spread_deg=1.5, radius=(30.0, 60.0), height=(300.0, 700.0)))):
     cfg, tiles = synth.scene("S2", 48, 24, generator="Rectilinear", **kw)

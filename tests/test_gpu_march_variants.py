@@ -69,7 +69,7 @@ def test_general_tracer_on_the_probe_scenes_against_the_oracle():
     """The two witness scenes of profiles/r04/ipra/README.md through k_rect_trace (ATMRT_MARCH_VARIANT=plain: a small frame otherwise
     takes the small-launch march and never reaches the tracer), every field AND the ray-step count against the oracle.  These are
     the scenes on which a tracer built with the default register allocator is wrong — with IPRA on (656 of 993 hits) and, capped at
-    128 VGPRs, with IPRA off (every ray credited with its wavefront's longest ray) — while the variant test above still passes."""
+    128 VGPRs, with IPRA off (ray-step counts beyond what a ray can have) — while the variant test above still passes."""
     env = dict(os.environ, ATMRT_MARCH_VARIANT="plain")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_waves_probe.py")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]

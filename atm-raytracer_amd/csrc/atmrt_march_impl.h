@@ -1020,12 +1020,12 @@ static __device__ __attribute__((noinline)) void step_object_pred(StepHits& sh, 
   }
 }
 #endif
-// 4 waves per SIMD (128 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above) — and ONLY with the VGPR allocator that
-// never splits a live range (csrc/Makefile TRACE_RA).  With the default allocator this kernel at 128 VGPRs counts wrong ray-steps
-// and azimuths in object scenes with interprocedural register allocation already OFF (round 4: full-size config 5 through 8 tiles,
-// seed 500011 of the random sweep, tools/trace_waves_probe.py), the second trigger of the failure that IPRA alone was blamed for;
-// profiles/r04/ipra/README.md has the ablations.  This loop is the pattern they point at: lanes leave it one by one (break) while
-// the others go on through out-of-line calls, around which the splitting allocator moves values from register to register.
+// 4 waves per SIMD (128 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above) — built with the VGPR allocator that never
+// splits a live range (csrc/Makefile TRACE_RA).  With the default allocator this kernel at 128 VGPRs is wrong in object scenes with
+// interprocedural register allocation already OFF (azimuth 0 for the rays without candidate objects, garbage step counts: round 4,
+// full-size config 5 through 8 tiles, seed 500011 of the sweep, tools/trace_waves_probe.py): the compiler stores `direction`, `p`
+// and `ncand` to their spill slots at the head of the block that follows the x_wake loop over the ray's candidates below, AHEAD of the
+// exec restore, i.e. only for the lanes that have candidates.  profiles/r04/ipra/README.md part 3; `make check-isa` finds such blocks in any build.
 #ifndef ATMRT_TRACE_WAVES
 #define ATMRT_TRACE_WAVES 4
 #endif

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "tools", "isa_prologue_spills.py")
-FIX = os.path.join(ROOT, "tests", "golden", "isa")
+FIX = os.path.join(ROOT, "tests", "golden", "asm_listings")
 CSRC = os.path.join(ROOT, "atm-raytracer_amd", "csrc")
 
 
@@ -20,10 +20,10 @@ def _check(path):
     return p.returncode, p.stdout
 
 
-@pytest.mark.parametrize("name,label,slots", [("bad_128vgpr_LBB8_267.s", ".LBB8_267", ("1564", "1752", "1744")),
-                                              ("bad_ipra_on_LBB8_1691.s", ".LBB8_1691", ("1400", "1352", "1344"))])
+@pytest.mark.parametrize("name,label,slots", [("bad_128vgpr_LBB8_267.asm", ".LBB8_267", ("1564", "1752", "1744")),
+                                              ("bad_ipra_on_LBB8_1691.asm", ".LBB8_1691", ("1400", "1352", "1344"))])
 def test_checker_flags_the_two_failing_builds(name, label, slots):
-    """The block of each failing build of round 4, as the compiler printed it (tests/golden/isa: excerpts of `hipcc -S` output for
+    """The block of each failing build of round 4, as the compiler printed it (tests/golden/asm_listings: excerpts of `hipcc -S` output for
     this repository's own k_rect_trace): three spill stores ahead of the exec restore."""
     rc, out = _check(os.path.join(FIX, name))
     assert rc == 1 and label in out and all(f"offset:{s} " in out for s in slots), out
@@ -32,7 +32,7 @@ def test_checker_flags_the_two_failing_builds(name, label, slots):
 
 def test_checker_passes_the_same_block_with_the_restore_first(tmp_path):
     """What the compiler should have emitted: the same instructions, the exec restore ahead of the stores."""
-    lines = open(os.path.join(FIX, "bad_128vgpr_LBB8_267.s")).read().splitlines()
+    lines = open(os.path.join(FIX, "bad_128vgpr_LBB8_267.asm")).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(".LBB8_267:"))
     restore = next(i for i in range(start, len(lines)) if "s_or_b64 exec, exec, s[2:3]" in lines[i])
     fixed = lines[:start + 1] + [lines[restore]] + lines[start + 1:restore] + lines[restore + 1:]

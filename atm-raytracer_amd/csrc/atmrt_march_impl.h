@@ -1003,23 +1003,6 @@ static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Eart
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
 // utils.rs:72-88), then the step logic above.
-#ifdef ATMRT_UNIFORM_CALL
-// step_object_impl for a call that every lane of the wavefront makes: the lanes that have an object to test say so (EXPERIMENT, below)
-static __device__ __attribute__((noinline)) void step_object_pred(StepHits& sh, const ObjectDev* objects, const uint8_t* textures, int idx,
-                                                                  Vec3 pos1, Vec3 pos2, bool need) {
-  if (!need) return;
-  Collision col[4];
-  int nc = object_collision(objects[idx], textures, pos1, pos2, col);
-  for (int q = 0; q < nc; q++) {
-    if (col[q].color[3] == 0.0) continue;
-    step_push(sh, col[q].prop, idx, &col[q]);
-    if (col[q].color[3] == 1.0) {
-      sh.finish = true;
-      break;
-    }
-  }
-}
-#endif
 // 4 waves per SIMD (128 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above) — built with the VGPR allocator that never
 // splits a live range (csrc/Makefile TRACE_RA).  With the default allocator this kernel at 128 VGPRs is wrong in object scenes with
 // interprocedural register allocation already OFF (azimuth 0 for the rays without candidate objects, garbage step counts: round 4,
@@ -1039,219 +1022,6 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
   // FILL = false: count the trace points of every pixel and keep those of pixels with <= RECT_SLOTS of them in the slot arena
   // (packed / rec / list_step then are that arena, entry p * RECT_SLOTS + j).  FILL = true: write every point at its place in
   // the pixel-ordered list, for all pixels or for the listed ones (those that did not fit their slots).
-#ifdef ATMRT_UNIFORM_CALL
-  // EXPERIMENT (profiles/r04/ipra/README.md; never defined in the product build): the same tracer with its out-of-line object call
-  // made WAVE-UNIFORM — every lane of the wavefront stays in the marching loop until the last ray has ended (a finished lane idles
-  // through it), and step_object_pred is called by all 64 lanes, predicated inside the callee.  With interprocedural register
-  // allocation on, the divergent call of step_object_impl loses trace points (round 2 / 3); this variant tests whether the call
-  // being entered under a partial exec mask is what that failure needs.
-  stage_dm_tables();
-  const size_t plane = (size_t)f.wl * f.h;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = pixel_list ? tid < n_list : tid < plane;
-  const size_t p = pixel_list ? (live ? pixel_list[tid] : 0) : tid;
-  unsigned long long steps = 0;
-  const Earth e = earth_for<CALC>(f);
-  const int y = (int)(p / (size_t)f.wl), x = (int)(p % (size_t)f.wl);
-  const bool sph = e.spherical != 0;
-  const double radius = e.shape_radius;
-  const bool straight = f.p.straight_rays != 0;
-  const double step = f.p.simulation_step, max_dist = f.p.frame.max_distance;
-  const bool terrain_opaque = f.p.terrain_alpha == 1.0;
-  const double skip_above = f.tv.skip_above;
-  const double alt = *f.alt;
-  double direction = 0.0, elevation = 0.0;
-  DirCalc c{};
-  Stepper s{};
-  unsigned count = 0;
-  uint64_t k = 0;
-  bool alive = false;
-  double lat0 = 0.0, lon0 = 0.0, te0 = 0.0;
-  int cand[CAND_CAP];
-  double clo[CAND_CAP], chi[CAND_CAP];
-  int ncand = 0;
-  bool use_cand = false;
-  unsigned m0 = 0u, m1 = 0u;
-  double x_wake = dm_inf();
-  double re0 = alt, d0 = 0.0, pl0 = 0.0, sx = 0.0, sh_ = alt, path_length = 0.0;
-  bool have0 = true;
-  if (live) {
-    rect_ray_params(f.p, f.ph, f.c0 + x, y, direction, elevation);
-    dircalc_new(e, f.p.position.latitude, f.p.position.longitude, dm_to_degrees(direction), c);
-    stepper_init(s, sph, radius, alt, elevation);
-    k = FILL ? hit_offset[p] : 0;
-    if (!(0.0 > max_dist || alt < -1000.0)) {
-      coords_at_dist(e, c, 0.0, lat0, lon0);
-      te0 = terrain_elev_or_zero(f.tv, lat0, lon0);
-      use_cand = ray_candidates<CALC, CAND_CAP>(f, e, c, cand, ncand, clo, chi);
-      if (!FILL && !use_cand && ncand == CAND_CAP) atomicAdd(&counters[4], 1ull);
-      m0 = use_cand ? close_mask(f, e, lat0, lon0, cand, ncand) : 0u;
-      for (int q = 0; q < ncand; q++)
-        if (chi[q] >= 0.0) x_wake = clo[q] < x_wake ? clo[q] : x_wake;
-      alive = true;
-    }
-  }
-  for (int i = 1; __any(alive); i++) {
-    StepHits hits;
-    hits.n = 0;
-    hits.finish = false;
-    bool any_object = false, crossing = false, have1 = false;
-    unsigned m = 0u;
-    double diff1 = 1.0, diff2 = 1.0, lat1 = 0.0, lon1 = 0.0, te1 = 0.0;
-    Vec3 pos1 = v3(0.0, 0.0, 0.0), pos2 = pos1;
-    LatLonTrig t0{}, t1{};
-    if (alive) {
-      bool tame;
-      RayState st = stepper_next<CUBIC>(s, *f.atm, sph, radius, straight, step, tame);
-      if (straight) tame = __all(calc_dist_in_band(*f.atm, sh_) && calc_dist_in_band(*f.atm, st.h));
-      path_length += calc_dist(sph, radius, sx, sh_, st.x, st.h, tame, f.inv_shape_radius);
-      sx = st.x;
-      sh_ = st.h;
-      if (sx > max_dist || sh_ < -1000.0 || !(sx <= max_dist)) alive = false; // rectilinear.rs:178 (+ NaN guard)
-    }
-    if (alive) {
-      const bool awake = use_cand && sx >= x_wake;
-      have1 = !use_cand || awake || !(sh_ > skip_above);
-      if (have1) {
-        coords_at_dist(e, c, sx, lat1, lon1);
-        te1 = terrain_elev_or_zero(f.tv, lat1, lon1);
-      }
-      m1 = 0u;
-      if (awake) {
-        m1 = close_mask(f, e, lat1, lon1, cand, ncand);
-        x_wake = dm_inf();
-        for (int q = 0; q < ncand; q++)
-          if (chi[q] >= sx) x_wake = clo[q] < x_wake ? clo[q] : x_wake;
-      }
-      steps++;
-      diff1 = have0 ? re0 - te0 : 1.0;
-      diff2 = have1 ? sh_ - te1 : 1.0;
-      crossing = diff1 * diff2 < 0.0;
-      if (use_cand) {
-        m = m0 | m1;
-        for (unsigned mm = m; mm; mm &= mm - 1)
-          if (object_out_of_band(f.objects[cand[__builtin_ctz(mm)]], re0, sh_)) m &= ~(mm & (0u - mm));
-        any_object = m != 0u;
-      } else {
-        any_object = f.n_objects != 0;
-      }
-      if ((crossing || any_object) && !(have0 && have1)) {
-#pragma unroll 1
-        for (int q = 0; q < 2; q++) {
-          if (q == 0 ? have0 : have1) continue;
-          double la, lo;
-          coords_at_dist(e, c, q == 0 ? d0 : sx, la, lo);
-          const double te = terrain_elev_or_zero(f.tv, la, lo);
-          if (q == 0) lat0 = la, lon0 = lo, te0 = te;
-          else lat1 = la, lon1 = lo, te1 = te;
-        }
-        have0 = have1 = true;
-        diff1 = re0 - te0;
-        diff2 = sh_ - te1;
-      }
-      if (crossing) {
-        step_push(hits, diff1 / (diff1 - diff2), -1, nullptr);
-        if (terrain_opaque) hits.finish = true;
-      }
-      if (any_object) {
-        pos1 = as_cartesian(e, lat0, lon0, re0);
-        pos2 = as_cartesian(e, lat1, lon1, sh_);
-        if (!use_cand) {
-          t0 = latlon_trig(e, lat0, lon0);
-          t1 = latlon_trig(e, lat1, lon1);
-        }
-      }
-    }
-    // ---- every lane of the wavefront is here: the out-of-line object code is called wave-uniformly ----
-    {
-      unsigned mm = (alive && any_object && use_cand) ? m : 0u;
-      while (__any(mm != 0u)) {
-        const bool need = mm != 0u;
-        const int j = need ? cand[__builtin_ctz(mm)] : 0;
-        step_object_pred(hits, f.objects, f.textures, j, pos1, pos2, need);
-        if (need) mm &= mm - 1;
-      }
-      if (__any(alive && any_object && !use_cand)) {
-        for (int j = 0; j < f.n_objects; j++) {
-          const bool need = alive && any_object && !use_cand && !object_out_of_band(f.objects[j], re0, sh_) &&
-                            (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1));
-          if (__any(need)) step_object_pred(hits, f.objects, f.textures, j, pos1, pos2, need);
-        }
-      }
-    }
-    if (alive) {
-      auto for_each_object = [&](auto&& visit) {
-        if (use_cand) {
-          for (unsigned mm = m; mm; mm &= mm - 1) visit(cand[__builtin_ctz(mm)]);
-        } else {
-          for (int j = 0; j < f.n_objects; j++)
-            if (!object_out_of_band(f.objects[j], re0, sh_) && (object_is_close(e, f.objects[j], t0) || object_is_close(e, f.objects[j], t1)))
-              visit(j);
-        }
-      };
-      if (!FILL) {
-        k = (uint64_t)p * RECT_SLOTS + count;
-        if (hits.n > STEP_CANDIDATES) atomicAdd(&counters[6], 1ull);
-      }
-      if (FILL && hits.n > STEP_CANDIDATES) {
-        const StepGeom g{lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx, path_length};
-        const uint64_t k0 = k;
-        if (crossing) big_step_put(packed, step_prop, k++, diff1 / (diff1 - diff2), nullptr, g);
-        for_each_object([&](int j) { big_step_object(packed, step_prop, k, f, j, pos1, pos2, g); });
-        big_step_sort(packed, step_prop, k0, hits.n);
-        for (uint64_t q = k0; q < k; q++) {
-          list_step[q] = (uint32_t)(i - 1);
-          list_pixel[q] = (uint32_t)p;
-          rec.re0[q] = re0;
-          rec.pl0[q] = pl0;
-          rec.re1[q] = sh_;
-          rec.pl1[q] = path_length;
-        }
-      } else if (hits.n && (FILL || count + (unsigned)hits.n <= (unsigned)RECT_SLOTS)) {
-        uint64_t k0 = k;
-        step_emit(hits, packed, list_step, list_pixel, k, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx, path_length);
-        for (uint64_t q = k0; q < k; q++) {
-          rec.re0[q] = re0;
-          rec.pl0[q] = pl0;
-          rec.re1[q] = sh_;
-          rec.pl1[q] = path_length;
-        }
-      } else if (!FILL && hits.n && hits.n <= STEP_CANDIDATES && ovf.cap) {
-        const unsigned long long base = atomicAdd(&counters[13], (unsigned long long)hits.n);
-        if (base + (unsigned long long)hits.n <= ovf.cap) {
-          uint64_t kk = base;
-          step_emit(hits, ovf_packed, ovf.step, ovf.pixel, kk, (uint32_t)p, i - 1, lat0, lon0, re0, d0, pl0, lat1, lon1, sh_, sx, path_length);
-          for (uint64_t q = base; q < kk; q++) {
-            ovf.ordinal[q] = count + (unsigned)(q - base);
-            ovf.re0[q] = re0;
-            ovf.pl0[q] = pl0;
-            ovf.re1[q] = sh_;
-            ovf.pl1[q] = path_length;
-          }
-        }
-      }
-      count += (unsigned)hits.n;
-      if (hits.finish) {
-        alive = false;
-      } else {
-        lat0 = lat1; lon0 = lon1; te0 = te1; re0 = sh_; d0 = sx; pl0 = path_length;
-        have0 = have1;
-        m0 = m1;
-      }
-    }
-  }
-  if (live && !FILL) {
-    out.azimuth[p] = dm_to_degrees(direction);
-    out.elevation_angle[p] = dm_to_degrees(elevation);
-    out.hit_count[p] = count;
-    if (count > (unsigned)RECT_SLOTS) atomicAdd(&counters[3], 1ull);
-  }
-  if (!FILL) {
-    steps = wave_sum(steps);
-    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
-  }
-}
-#else
   stage_dm_tables();
   const size_t plane = (size_t)f.wl * f.h;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1440,7 +1210,6 @@ __global__ __launch_bounds__(256, ATMRT_TRACE_WAVES) void k_rect_trace(Frame f, 
     if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&counters[0], steps);
   }
 }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // launchers

@@ -66,12 +66,12 @@ def test_all_march_variants_produce_the_same_frames():
 
 @pytest.mark.gpu
 def test_general_tracer_on_the_probe_scenes_against_the_oracle():
-    """The two witness scenes of profiles/r04/ipra/README.md through k_rect_trace (ATMRT_MARCH_VARIANT=plain: a small frame otherwise
+    """The witness scenes of profiles/r04/ipra/README.md through k_rect_trace (ATMRT_MARCH_VARIANT=plain: a small frame otherwise
     takes the small-launch march and never reaches the tracer), every field AND the ray-step count against the oracle.  These are
     the scenes on which a tracer built with the default register allocator is wrong — with IPRA on (656 of 993 hits) and, capped at
     128 VGPRs, with IPRA off (ray-step counts beyond what a ray can have) — while the variant test above still passes."""
     env = dict(os.environ, ATMRT_MARCH_VARIANT="plain")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_waves_probe.py")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith(("scene_objects", "per_lane_list"))]
-    assert len(lines) == 2 and all(l.endswith("identical") for l in lines), p.stdout
+    lines = [l for l in p.stdout.splitlines() if l.startswith(("scene_objects", "per_lane_list", "one_sided"))]
+    assert len(lines) == 3 and all(l.endswith("identical") for l in lines), p.stdout

@@ -62,3 +62,29 @@ def test_the_shipped_units_are_clean():
     """`make check-isa`: the device assembly of all nine units, every earth-model variant, with the flags the library is built with."""
     p = subprocess.run(["make", "-s", "-j8", "-C", CSRC, "check-isa"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "9 units clean" in p.stdout, (p.stdout + p.stderr)[-3000:]
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="needs llvm-objdump")
+@pytest.mark.parametrize("unit", ["atmrt_trace_linear", "atmrt_march_linear"])
+def test_the_listing_is_the_code_that_ships(unit, tmp_path):
+    """The guard reads `hipcc -S` output, the library links `hipcc -c` output: same flags, and the same instructions — the device code
+    object inside the shipped .o, disassembled, holds exactly as many spill stores, reloads, lane writes, calls, exec restores and FMAs
+    as the listing check-isa looked at."""
+    obj, lst = os.path.join(CSRC, unit + ".o"), os.path.join(CSRC, "isa", unit + ".s")
+    if not (os.path.exists(obj) and os.path.exists(lst)):
+        pytest.skip("library or listings not built (make -C atm-raytracer_amd/csrc; make check-isa)")
+    if os.path.getmtime(lst) < os.path.getmtime(os.path.join(CSRC, "atmrt_march_impl.h")):
+        pytest.skip("listing older than the sources: test_the_shipped_units_are_clean rebuilds it")
+    shutil.copy(obj, tmp_path / "u.o")
+    subprocess.run([OBJDUMP, "--offloading", "u.o"], cwd=tmp_path, check=True, capture_output=True)  # writes u.o.0.hipv4-amdgcn-...
+    co = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([OBJDUMP, "-d", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+    listing = open(lst).read()
+    for op in ("scratch_store_dword", "scratch_load_dword", "s_swappc_b64", "v_writelane_b32", "s_or_b64 exec, exec", "v_fma_f64", "v_rcp_f64"):
+        in_obj = sum(1 for l in dis.splitlines() if op in l)
+        in_lst = sum(1 for l in listing.splitlines() if l.lstrip().startswith(op))
+        assert in_obj == in_lst and in_obj > 0, (unit, op, in_obj, in_lst)

@@ -1003,8 +1003,8 @@ static __device__ __forceinline__ unsigned close_mask(const Frame& f, const Eart
 
 // Rectilinear, general.  Per sample: geodesic point, terrain gather, proximity filter (TerrainData::from_lat_lon,
 // utils.rs:72-88), then the step logic above.
-// 4 waves per SIMD (128 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above) — built with the VGPR allocator that never
-// splits a live range (csrc/Makefile TRACE_RA).  With the default allocator this kernel at 128 VGPRs is wrong in object scenes with
+// 4 waves per SIMD (128 VGPRs) with the object code out of line (see ATMRT_OBJ_FN above) — built with the register allocator's region
+// splitting off (csrc/Makefile TRACE_RA).  With the default allocator this kernel at 128 VGPRs is wrong in object scenes with
 // interprocedural register allocation already OFF (azimuth 0 for the rays without candidate objects, garbage step counts: round 4,
 // full-size config 5 through 8 tiles, seed 500011 of the sweep, tools/trace_waves_probe.py): the compiler stores `direction`, `p`
 // and `ncand` to their spill slots at the head of the block that follows the x_wake loop over the ray's candidates below, AHEAD of the

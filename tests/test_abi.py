@@ -53,8 +53,10 @@ def test_build_info_names_the_sources_and_the_required_flags(lib):
     info = _lib.build_info()
     assert info["source_hash"] == _lib.source_hash(), "libatmrt.so was not built from this tree: run make -C atm-raytracer_amd/csrc"
     assert "-enable-ipra=0" in info["calling_units"] and "-disable-machine-licm" in info["march_units"] and info["arch"] == "gfx950"
-    # round 4 (profiles/r04/ipra/README.md): no live-range splitting around the calls of the loops that lanes leave one by one
-    assert "-vgpr-regalloc=basic" in info["trace_units"] and "-grow-region-complexity-budget=0" in info["march_units"]
+    # round 4 (profiles/r04/ipra/README.md part 3): the units under register pressure are built without the splitting that asks for spill
+    # code at block heads (hipcc 7.2 can put it ahead of the block's exec restore); make check-isa verifies the result
+    split_off = ("-grow-region-complexity-budget=0", "-vgpr-regalloc=basic")  # region splitting off, or the allocator that never splits
+    assert any(f in info["trace_units"] for f in split_off) and any(f in info["march_units"] for f in split_off)
     assert "-ffp-contract=off" in info["all"]
 
 
